@@ -1,0 +1,106 @@
+"""Seeded synthetic weights and frames (there is no network for checkpoints or datasets).
+
+Tensor names follow the checkpoints the reference loads (HF Qwen2 names under
+``model.``/``lm_head``, the three head names of
+models/live_llava/video_head_live_llava_qwen.py:83-85, ``mm_projector.{0,2}`` of the
+llava ``mlp2x_gelu`` projector, SigLIP names under ``vision.``), so the same dict format
+serves a real safetensors loader later.  Per-tensor seed = crc32(name) (SURVEY.md 8d:
+never Python's salted ``hash``).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterator, Tuple
+
+import torch
+
+from .config import LiveConfig
+
+
+def tensor_specs(cfg: LiveConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
+    """Yield (name, shape, kind) with kind in {'w','b','norm_w','norm_b','qkv_b','emb'}."""
+    v, lm = cfg.vision, cfg.lm
+    Dv, H = v.hidden_size, lm.hidden_size
+    yield "vision.embeddings.patch_embedding.weight", (Dv, 3, v.patch_size, v.patch_size), "w"
+    yield "vision.embeddings.patch_embedding.bias", (Dv,), "b"
+    yield "vision.embeddings.position_embedding.weight", (v.num_patches, Dv), "emb"
+    for i in range(v.num_hidden_layers):
+        p = f"vision.encoder.layers.{i}."
+        yield p + "layer_norm1.weight", (Dv,), "norm_w"
+        yield p + "layer_norm1.bias", (Dv,), "norm_b"
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            yield p + f"self_attn.{n}.weight", (Dv, Dv), "w"
+            yield p + f"self_attn.{n}.bias", (Dv,), "b"
+        yield p + "layer_norm2.weight", (Dv,), "norm_w"
+        yield p + "layer_norm2.bias", (Dv,), "norm_b"
+        yield p + "mlp.fc1.weight", (v.intermediate_size, Dv), "w"
+        yield p + "mlp.fc1.bias", (v.intermediate_size,), "b"
+        yield p + "mlp.fc2.weight", (Dv, v.intermediate_size), "w"
+        yield p + "mlp.fc2.bias", (Dv,), "b"
+    yield "mm_projector.0.weight", (H, Dv), "w"
+    yield "mm_projector.0.bias", (H,), "b"
+    yield "mm_projector.2.weight", (H, H), "w"
+    yield "mm_projector.2.bias", (H,), "b"
+    yield "model.embed_tokens.weight", (lm.vocab_size, H), "emb"
+    qd, kd = lm.num_attention_heads * lm.head_dim, lm.num_key_value_heads * lm.head_dim
+    for i in range(lm.num_hidden_layers):
+        p = f"model.layers.{i}."
+        yield p + "input_layernorm.weight", (H,), "norm_w"
+        yield p + "self_attn.q_proj.weight", (qd, H), "w"
+        yield p + "self_attn.q_proj.bias", (qd,), "qkv_b"
+        yield p + "self_attn.k_proj.weight", (kd, H), "w"
+        yield p + "self_attn.k_proj.bias", (kd,), "qkv_b"
+        yield p + "self_attn.v_proj.weight", (kd, H), "w"
+        yield p + "self_attn.v_proj.bias", (kd,), "qkv_b"
+        yield p + "self_attn.o_proj.weight", (H, qd), "w"
+        yield p + "post_attention_layernorm.weight", (H,), "norm_w"
+        yield p + "mlp.gate_proj.weight", (lm.intermediate_size, H), "w"
+        yield p + "mlp.up_proj.weight", (lm.intermediate_size, H), "w"
+        yield p + "mlp.down_proj.weight", (H, lm.intermediate_size), "w"
+    yield "model.norm.weight", (H,), "norm_w"
+    yield "lm_head.weight", (lm.vocab_size, H), "w"
+    yield "informative_head.weight", (2, H), "w"
+    yield "relevance_head.weight", (1, H), "w"
+    yield "uncertainty_head.weight", (1, H), "w"
+
+
+def make_weights(cfg: LiveConfig, *, device="cpu", dtype=torch.bfloat16, jitter: bool = False,
+                 std: float = 0.02, skip_lm_head: bool = False) -> Dict[str, torch.Tensor]:
+    """normal(0, std) matrices, norm weights 1, biases 0 except q/k/v bias ~ normal(0, std)
+    (SURVEY.md 8d config 2).  ``jitter`` perturbs norm weights/biases and linear biases so
+    parity tests exercise those terms too.  Values are drawn in fp32 then cast to ``dtype``.
+    """
+    out: Dict[str, torch.Tensor] = {}
+    dev = torch.device(device)
+    for name, shape, kind in tensor_specs(cfg):
+        if skip_lm_head and name == "lm_head.weight":
+            continue
+        g = torch.Generator(device=dev)
+        g.manual_seed(zlib.crc32(name.encode()))
+        if kind in ("w", "emb", "qkv_b"):
+            t = torch.empty(shape, device=dev, dtype=torch.float32).normal_(0.0, std, generator=g)
+        elif kind == "norm_w":
+            t = torch.ones(shape, device=dev, dtype=torch.float32)
+            if jitter:
+                t += torch.empty(shape, device=dev, dtype=torch.float32).normal_(0.0, 0.1, generator=g)
+        else:  # 'b', 'norm_b'
+            t = torch.zeros(shape, device=dev, dtype=torch.float32)
+            if jitter:
+                t += torch.empty(shape, device=dev, dtype=torch.float32).normal_(0.0, std, generator=g)
+        out[name] = t.to(dtype)
+    return out
+
+
+def make_frames(n: int, resolution: int, *, seed: int = 0, device="cpu") -> torch.Tensor:
+    """uint8 [n,3,S,S] RGB CHW, the layout load_video_for_testing hands to the driver
+    (test/inference.py:497-582)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    f = torch.randint(0, 256, (n, 3, resolution, resolution), generator=g, dtype=torch.uint8)
+    return f.to(device)
+
+
+def make_token_ids(n: int, vocab: int, *, seed: int) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randint(0, vocab, (1, n), generator=g, dtype=torch.long)

@@ -1,0 +1,113 @@
+"""ORACLE (test infrastructure, never shipped or measured as the product).
+
+CPU restatement of the vision half of the reference's per-frame path:
+
+  image_processor.preprocess            test/inference.py:176 (impl in the un-vendored
+                                        LLaVA-NeXT submodule: x/255 then (x-.5)/.5)
+  vision_encode -> vision_tower         models/live_llava/video_head_live_llava_qwen.py:113-115
+  connector (mm_projector, mlp2x_gelu)  video_head_live_llava_qwen.py:107-108
+  post_projector_pooling                video_head_live_llava_qwen.py:117-136
+  visual_embed                          models/modeling_live.py:31-37
+  _siglip_vision_encode (dead-code spec) models/vision_live.py:11-31
+
+LLaVA-NeXT is absent from /root/reference (empty submodule dir), so the tower arithmetic
+is restated from the published SigLIP architecture as implemented by the local
+transformers copy, transformers/models/siglip/modeling_siglip.py:116-358 (embeddings
+:116-186, attention :251-308, MLP :312-324, layer :327-358): the llava tower returns the
+last executed encoder layer's hidden state with no post-layernorm and no pooling head.
+
+Pinned by tests/test_oracle_vision.py against local transformers SiglipVisionModel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def preprocess(frames_u8: torch.Tensor, dtype) -> torch.Tensor:
+    """uint8 [N,3,S,S] -> working dtype; rescale 1/255 then normalize mean .5 std .5 in fp32
+    (vision_live.py:11-13 states the same constants)."""
+    x = frames_u8.to(torch.float32) * 0.00392156862745098
+    x = (x - 0.5) / 0.5
+    return x.to(dtype)
+
+
+class OracleVision:
+    def __init__(self, cfg, weights: Dict[str, torch.Tensor], dtype=torch.bfloat16) -> None:
+        """cfg: aha_amd.config.LiveConfig-like (needs .vision, .lm.hidden_size, pooling knobs)."""
+        self.cfg = cfg
+        self.v = cfg.vision
+        self.dtype = dtype
+        self.w = {k: t.to(dtype) for k, t in weights.items() if k.startswith(("vision.", "mm_projector."))}
+
+    @torch.no_grad()
+    def tower(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """[N,3,S,S] working dtype -> [N,Np,Dv] (modeling_siglip.py:176-186, 327-358)."""
+        v, w = self.v, self.w
+        x = F.conv2d(pixel_values, w["vision.embeddings.patch_embedding.weight"],
+                     w["vision.embeddings.patch_embedding.bias"], stride=v.patch_size)
+        x = x.flatten(2).transpose(1, 2)
+        x = x + w["vision.embeddings.position_embedding.weight"][None]
+        N, Np, Dv = x.shape
+        nh, hd = v.num_attention_heads, v.head_dim
+        for i in range(v.num_hidden_layers):
+            p = f"vision.encoder.layers.{i}."
+            r = x
+            h = F.layer_norm(x, (Dv,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], v.layer_norm_eps)
+            q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
+            k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"])
+            vv = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
+            q = q.view(N, Np, nh, hd).transpose(1, 2)
+            k = k.view(N, Np, nh, hd).transpose(1, 2)
+            vv = vv.view(N, Np, nh, hd).transpose(1, 2)
+            o = F.scaled_dot_product_attention(q, k, vv, scale=hd ** -0.5)
+            o = o.transpose(1, 2).reshape(N, Np, Dv)
+            o = F.linear(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+            x = r + o
+            r = x
+            h = F.layer_norm(x, (Dv,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], v.layer_norm_eps)
+            h = F.linear(h, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
+            h = F.gelu(h, approximate="tanh")
+            h = F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+            x = r + h
+        return x
+
+    @torch.no_grad()
+    def connector(self, feats: torch.Tensor) -> torch.Tensor:
+        """mlp2x_gelu: Linear(Dv->H), GELU (exact erf), Linear(H->H)."""
+        w = self.w
+        h = F.linear(feats, w["mm_projector.0.weight"], w["mm_projector.0.bias"])
+        h = F.gelu(h)
+        return F.linear(h, w["mm_projector.2.weight"], w["mm_projector.2.bias"])
+
+    @torch.no_grad()
+    def post_projector_pooling(self, image_feature: torch.Tensor) -> torch.Tensor:
+        """video_head_live_llava_qwen.py:117-136."""
+        stride = self.cfg.video_pooling_stride
+        g = self.v.grid
+        n, _, d = image_feature.shape
+        x = image_feature.view(n, g, g, -1).permute(0, 3, 1, 2).contiguous()
+        mode = self.cfg.mm_spatial_pool_mode
+        if mode == "average":
+            x = F.avg_pool2d(x, stride)
+        elif mode == "max":
+            x = F.max_pool2d(x, stride)
+        elif mode == "bilinear":
+            hh, ww = x.shape[2:]
+            x = F.interpolate(x, size=[math.ceil(hh / stride), math.ceil(ww / stride)], mode="bilinear")
+        else:
+            raise ValueError(f"Unexpected mm_spatial_pool_mode: {mode}")
+        x = x.permute(0, 2, 3, 1)
+        return x.reshape(n, -1, d).contiguous()
+
+    @torch.no_grad()
+    def visual_embed(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 frames -> [N*Tf, H] (modeling_live.py:31-37 after test/inference.py:176)."""
+        x = preprocess(frames_u8, self.dtype)
+        x = self.tower(x)
+        x = self.connector(x)
+        x = self.post_projector_pooling(x)
+        return x.reshape(-1, x.shape[-1])

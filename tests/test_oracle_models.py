@@ -1,0 +1,131 @@
+"""Pin oracle/qwen2_live.py and oracle/vision_tower.py against local transformers
+(Qwen2Model + DynamicCache, SiglipVisionModel) live, and against the committed fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+import aha_amd  # noqa: F401
+from aha_amd.config import preset
+from aha_amd.synth import make_frames, make_weights
+from oracle.cache_policies import GrowingPolicy, SinkPolicy, SlidingPolicy, StaticPolicy
+from oracle.qwen2_live import OracleLM, frame_scores
+from oracle.vision_tower import OracleVision, preprocess
+
+
+def _hf_qwen2(lm, w, dt, impl):
+    from transformers import Qwen2Config, Qwen2Model
+    hc = Qwen2Config(hidden_size=lm.hidden_size, num_hidden_layers=lm.num_hidden_layers,
+                     num_attention_heads=lm.num_attention_heads, num_key_value_heads=lm.num_key_value_heads,
+                     intermediate_size=lm.intermediate_size, vocab_size=lm.vocab_size, rope_theta=lm.rope_theta,
+                     rms_norm_eps=lm.rms_norm_eps, max_position_embeddings=lm.max_position_embeddings,
+                     head_dim=lm.head_dim, attn_implementation=impl)
+    m = Qwen2Model(hc).to(dt).eval()
+    m.load_state_dict({k[len("model."):]: v for k, v in w.items() if k.startswith("model.")})
+    return hc, m
+
+
+def test_lm_matches_golden_fp32():
+    gold = np.load(os.path.join(GOLDEN, "qwen2_tiny_steps.npz"))
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    o = OracleLM(cfg.lm, w, torch.float32)
+    cache = GrowingPolicy()
+    g = torch.Generator().manual_seed(3)
+    for step, T in enumerate(gold["steps"].tolist()):
+        x = torch.randn(1, T, cfg.lm.hidden_size, generator=g)
+        y = o.step(x, cache)["hidden"]
+        np.testing.assert_allclose(y.numpy(), gold[f"hidden_s{step}"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("preset_name", ["tiny", "tiny128"])
+@pytest.mark.parametrize("impl", ["sdpa", "eager"])
+def test_lm_matches_transformers_live(preset_name, impl):
+    from transformers import DynamicCache
+    cfg = preset(preset_name)
+    w32 = make_weights(cfg, dtype=torch.float32, jitter=True)
+    for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 0.07)):
+        w = {k: v.to(dt) for k, v in w32.items()}
+        hc, m = _hf_qwen2(cfg.lm, w, dt, impl)
+        o = OracleLM(cfg.lm, w, dt, attn_impl=impl)
+        ch, co = DynamicCache(config=hc), GrowingPolicy()
+        g = torch.Generator().manual_seed(11)
+        for T in [7, 4, 4, 1, 4]:
+            x = torch.randn(1, T, cfg.lm.hidden_size, generator=g).to(dt)
+            with torch.no_grad():
+                yh = m(inputs_embeds=x, past_key_values=ch, use_cache=True).last_hidden_state
+            yo = o.step(x, co)["hidden"]
+            assert ch.get_seq_length() == co.get_seq_length()
+            assert (yh.float() - yo.float()).abs().max().item() <= tol
+
+
+def test_vision_matches_golden_and_transformers():
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    gold = np.load(os.path.join(GOLDEN, "siglip_tiny.npz"))
+    cfg = preset("tiny")
+    v = cfg.vision
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    fr = make_frames(2, v.image_size, seed=0)
+    ov = OracleVision(cfg, w, torch.float32)
+    y = ov.tower(preprocess(fr, torch.float32))
+    np.testing.assert_allclose(y.numpy(), gold["hidden"], rtol=0, atol=2e-5)
+    vc = SiglipVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                            num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                            image_size=v.image_size, patch_size=v.patch_size, layer_norm_eps=v.layer_norm_eps,
+                            hidden_act="gelu_pytorch_tanh", attn_implementation="sdpa")
+    for dt in (torch.float32, torch.bfloat16):
+        vm = SiglipVisionModel(vc).to(dt).eval()
+        vm.load_state_dict({k[len("vision."):]: t.to(dt) for k, t in w.items() if k.startswith("vision.")}, strict=False)
+        px = preprocess(fr, dt)
+        with torch.no_grad():
+            hs = vm(pixel_values=px, output_hidden_states=True).hidden_states[-1]
+        yo = OracleVision(cfg, w, dt).tower(px)
+        assert (hs.float() - yo.float()).abs().max().item() <= (2e-5 if dt == torch.float32 else 0.04)
+
+
+def test_visual_embed_shapes_and_pool():
+    for name, tf in (("tiny", 4), ("tiny128", 9)):
+        cfg = preset(name)
+        assert cfg.frame_num_tokens == tf
+        w = make_weights(cfg, dtype=torch.float32, jitter=True)
+        ov = OracleVision(cfg, w, torch.float32)
+        e = ov.visual_embed(make_frames(3, cfg.vision.image_size, seed=1))
+        assert e.shape == (3 * tf, cfg.lm.hidden_size)
+    assert preset("bench").frame_num_tokens == 36 and preset("ref").frame_num_tokens == 49
+
+
+@pytest.mark.parametrize("policy", ["sink", "sliding", "static", "none"])
+def test_policies_run_through_lm_and_positions(policy):
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    o = OracleLM(cfg.lm, w, torch.float32)
+    cache = {"sink": SinkPolicy(24, 4), "sliding": SlidingPolicy(24), "static": StaticPolicy(24),
+             "none": GrowingPolicy()}[policy]
+    g = torch.Generator().manual_seed(5)
+    lens = []
+    for T in [10, 4, 4, 4, 4, 4, 4]:
+        out = o.step(torch.randn(1, T, cfg.lm.hidden_size, generator=g), cache)
+        s = frame_scores(out)
+        assert s.shape == (1, 3) and torch.isfinite(s).all()
+        assert 0 < s[0, 0] < 1 and 0 < s[0, 1] < 1 and s[0, 2] > 0
+        lens.append(cache.get_seq_length())
+    want = {"sink": [10, 14, 18, 22, 24, 24, 24], "sliding": [10, 14, 18, 22, 24, 24, 24],
+            "static": [10] * 7, "none": [10, 14, 18, 22, 26, 30, 34]}[policy]
+    assert lens == want
+
+
+def test_static_frozen_sees_prefix_only():
+    """After the first call a StaticPolicy step must not depend on earlier frame steps
+    (test/static_cache.py:26-36: the cache never changes again)."""
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    o = OracleLM(cfg.lm, w, torch.float32)
+    g = torch.Generator().manual_seed(9)
+    prefix = torch.randn(1, 6, cfg.lm.hidden_size, generator=g)
+    a, b = torch.randn(1, 4, cfg.lm.hidden_size, generator=g), torch.randn(1, 4, cfg.lm.hidden_size, generator=g)
+    c1, c2 = StaticPolicy(32), StaticPolicy(32)
+    o.step(prefix, c1), o.step(prefix, c2)
+    o.step(a, c1)
+    assert torch.equal(o.step(b, c1)["hidden"], o.step(b, c2)["hidden"])
