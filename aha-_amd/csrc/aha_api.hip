@@ -1,0 +1,806 @@
+// C-ABI of the streaming path (include/aha_amd.h): context, weight repacking, per-stream KV
+// state machines (the reference's cache policies as ring bookkeeping), and the orchestration of
+// the gfx950 kernels for aha_vit_encode / aha_lm_step.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/aha_amd.h"
+#include "aha_kernels.h"
+
+#define AHA_E_INVAL (-22)
+#define AHA_E_NOMEM (-12)
+#define AHA_E_HIP (-5)
+#define AHA_E_RANGE (-34)
+#define AHA_E_NOENT (-2)
+
+struct PackedW {
+    bf16x8* p = nullptr;
+    int n_tiles = 0, KS = 0, N = 0, K = 0;
+    double bytes() const { return (double)n_tiles * KS * 1024.0; }
+};
+struct LayerW {
+    PackedW qkv, o, gateup, down;
+    bf16 *qkv_bias = nullptr, *ln1 = nullptr, *ln2 = nullptr;
+};
+struct VLayerW {
+    bf16 *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
+};
+enum { GK_QKV = 0, GK_O = 1, GK_GATEUP = 2, GK_DOWN = 3, GK_COUNT = 4 };
+
+struct aha_ctx {
+    aha_model_desc d;
+    int device = 0;
+    std::string err;
+    int grid = 0, Np = 0, Kp = 0, go = 0, Tf = 0;
+    bool weights_loaded = false;
+    // LM weights
+    std::vector<LayerW> L;
+    bf16 *final_norm = nullptr, *heads_w = nullptr, *embed = nullptr;
+    PackedW lm_head;
+    // vision weights
+    bf16 *patch_w = nullptr, *patch_b = nullptr, *pos_emb = nullptr;
+    std::vector<VLayerW> V;
+    bf16 *p0w = nullptr, *p0b = nullptr, *p2w = nullptr, *p2b = nullptr;
+    // tables
+    bf16 *rope_cos = nullptr, *rope_sin = nullptr;
+    int n_pos = 0;
+    std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
+    // LM workspaces
+    bf16 *h = nullptr, *xn = nullptr, *q_rot = nullptr, *attn_out = nullptr, *act = nullptr;
+    float *partial = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *heads_tmp = nullptr;
+    size_t partial_floats = 0, part_o_floats = 0;
+    int last_B = 0, last_T = 0;
+    // ViT workspaces
+    bf16 *v_a0 = nullptr, *v_x = nullptr, *v_h = nullptr, *v_qkv = nullptr, *v_attn = nullptr, *v_f = nullptr,
+         *v_p1 = nullptr, *v_p2 = nullptr;
+    // tuning
+    int split[GK_COUNT] = {0, 0, 0, 0};
+    int attn_split_len = 0;
+    int time_gemm = 0;
+    // accounting of the last step
+    double last_weight_bytes = 0, last_kv_bytes = 0, last_flops = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GK_COUNT];
+    int ev_used[GK_COUNT] = {0, 0, 0, 0};
+    double gk_bytes[GK_COUNT] = {0, 0, 0, 0};
+    std::vector<void*> allocs;
+};
+
+struct aha_stream {
+    aha_ctx* ctx;
+    int policy, W, sink, cap;
+    bf16 *k = nullptr, *v = nullptr;
+    int len = 0, head = 0, seen = 0;
+    int semantics = AHA_ATTN_TRAILING;
+};
+
+static int fail(aha_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+#define HIPCHK(c, expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), AHA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+static int dalloc(aha_ctx* c, T** out, size_t count) {
+    void* p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return fail(c, AHA_E_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    c->allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+extern "C" const char* aha_version(void) { return "aha_amd 0.1 (gfx950)"; }
+
+extern "C" const char* aha_last_error(aha_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out) {
+    if (!d || !out) return AHA_E_INVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return AHA_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return AHA_E_HIP;
+    aha_ctx* c = new aha_ctx();
+    c->d = *d;
+    c->device = device;
+    *out = c;
+    const int Dh = d->head_dim;
+    if (Dh != 64 && Dh != 128) return fail(c, AHA_E_INVAL, "LM head_dim must be 64 or 128");
+    if (d->hidden % 32 || d->inter % 32 || (d->heads * Dh) % 32) return fail(c, AHA_E_INVAL, "LM dims must be multiples of 32");
+    if (d->heads % d->kv_heads) return fail(c, AHA_E_INVAL, "heads %% kv_heads != 0");
+    const int vhd = d->v_hidden / d->v_heads;
+    if (vhd != 64 && vhd != 128) return fail(c, AHA_E_INVAL, "vision head_dim must be 64 or 128 (so400m's 72 not yet supported)");
+    if (d->v_hidden % 8 || d->v_inter % 8 || d->v_hidden > 4096) return fail(c, AHA_E_INVAL, "vision dims must be multiples of 8, width <= 4096");
+    if (d->hidden > 8192) return fail(c, AHA_E_INVAL, "hidden > 8192 unsupported");
+    c->grid = d->image_size / d->patch_size;
+    c->Np = c->grid * c->grid;
+    c->Kp = round_up(3 * d->patch_size * d->patch_size, 8);
+    c->go = d->pool_mode == 0 ? ceil_div(c->grid, d->pool_stride) : c->grid / d->pool_stride;
+    c->Tf = c->go * c->go;
+
+    // ---- LM workspaces
+    const size_t M = (size_t)d->max_step_tokens, H = d->hidden, QD = (size_t)d->heads * Dh, I = d->inter;
+    const int G = d->heads / d->kv_heads;
+    int rc;
+    if ((rc = dalloc(c, &c->h, M * H))) return rc;
+    if ((rc = dalloc(c, &c->xn, M * H))) return rc;
+    if ((rc = dalloc(c, &c->q_rot, M * QD))) return rc;
+    if ((rc = dalloc(c, &c->attn_out, M * QD))) return rc;
+    if ((rc = dalloc(c, &c->act, M * I))) return rc;
+    const size_t nqkv = round_up((d->heads + 2 * d->kv_heads) * Dh, 16);
+    c->partial_floats = 16 * M * (nqkv > H ? nqkv : H);       // up to 16 split-K slabs
+    if ((rc = dalloc(c, &c->partial, c->partial_floats))) return rc;
+    const size_t rows_pad = (size_t)G * M + 16 * AHA_MAX_B;
+    c->part_o_floats = (size_t)d->kv_heads * 16 * rows_pad * Dh;   // up to 16 key splits
+    if ((rc = dalloc(c, &c->part_o, c->part_o_floats))) return rc;
+    if ((rc = dalloc(c, &c->part_ml, (size_t)d->kv_heads * 16 * rows_pad * 2))) return rc;
+    if ((rc = dalloc(c, &c->logits, (size_t)AHA_MAX_B * d->vocab))) return rc;
+    if ((rc = dalloc(c, &c->heads_tmp, M * 4))) return rc;
+
+    // ---- ViT workspaces
+    const size_t R = (size_t)d->max_vit_frames * c->Np, Dv = d->v_hidden;
+    if ((rc = dalloc(c, &c->v_a0, R * c->Kp))) return rc;
+    if ((rc = dalloc(c, &c->v_x, R * Dv))) return rc;
+    if ((rc = dalloc(c, &c->v_h, R * Dv))) return rc;
+    if ((rc = dalloc(c, &c->v_qkv, R * 3 * Dv))) return rc;
+    if ((rc = dalloc(c, &c->v_attn, R * Dv))) return rc;
+    if ((rc = dalloc(c, &c->v_f, R * d->v_inter))) return rc;
+    if ((rc = dalloc(c, &c->v_p1, R * H))) return rc;
+    if ((rc = dalloc(c, &c->v_p2, R * H))) return rc;
+    return 0;
+}
+
+extern "C" void aha_ctx_destroy(aha_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->allocs) hipFree(p);
+    for (int k = 0; k < GK_COUNT; ++k)
+        for (auto& pr : c->ev[k]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete c;
+}
+
+extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
+    if (!c || !key) return AHA_E_INVAL;
+    std::string k(key);
+    if (k == "split_qkv") c->split[GK_QKV] = value;
+    else if (k == "split_o") c->split[GK_O] = value;
+    else if (k == "split_gateup") c->split[GK_GATEUP] = value;   // ignored by the fused SwiGLU epilogue (always 1)
+    else if (k == "split_down") c->split[GK_DOWN] = value;
+    else if (k == "attn_split_len") c->attn_split_len = value;
+    else if (k == "time_gemm") c->time_gemm = value;
+    else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// weights
+// --------------------------------------------------------------------------------------------
+typedef std::unordered_map<std::string, const aha_tensor_view*> TMap;
+
+static const aha_tensor_view* need(aha_ctx* c, const TMap& m, const std::string& name, int ndim, int64_t d0, int64_t d1) {
+    auto it = m.find(name);
+    if (it == m.end()) { c->err = "missing tensor " + name; return nullptr; }
+    const aha_tensor_view* t = it->second;
+    int64_t numel = 1;
+    for (int i = 0; i < t->ndim; ++i) numel *= t->shape[i];
+    int64_t want = d0 * (ndim > 1 ? d1 : 1);
+    if (numel != want) { c->err = "bad shape for " + name; return nullptr; }
+    return t;
+}
+
+static int copy_vec(aha_ctx* c, const TMap& m, const std::string& name, int64_t n, bf16** dst, hipStream_t st) {
+    const aha_tensor_view* t = need(c, m, name, 1, n, 1);
+    if (!t) return AHA_E_NOENT;
+    int rc = dalloc(c, dst, (size_t)n);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(*dst, t->data, n * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int alloc_packed(aha_ctx* c, PackedW* w, int n_tiles, int K) {
+    w->n_tiles = n_tiles;
+    w->K = K;
+    w->KS = K / 32;
+    return dalloc(c, &w->p, (size_t)n_tiles * w->KS * 64);
+}
+
+static int pack_into(aha_ctx* c, const TMap& m, const std::string& name, int N, int K, PackedW* w, int tile_stride,
+                     int tile_off, hipStream_t st) {
+    const aha_tensor_view* t = need(c, m, name, 2, N, K);
+    if (!t) return AHA_E_NOENT;
+    HIPCHK(c, aha_pack_w((const bf16*)t->data, N, K, K, w->p, w->KS, tile_stride, tile_off, st));
+    return 0;
+}
+
+extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, size_t n, aha_hip_stream st_) {
+    if (!c || !tensors) return AHA_E_INVAL;
+    hipStream_t st = (hipStream_t)st_;
+    HIPCHK(c, hipSetDevice(c->device));
+    TMap m;
+    for (size_t i = 0; i < n; ++i) m[tensors[i].name] = &tensors[i];
+    const aha_model_desc& d = c->d;
+    const int H = d.hidden, Dh = d.head_dim, QD = d.heads * Dh, KD = d.kv_heads * Dh, I = d.inter;
+    int rc;
+    // ---- LM
+    c->L.resize(d.layers);
+    for (int l = 0; l < d.layers; ++l) {
+        LayerW& w = c->L[l];
+        const std::string p = "model.layers." + std::to_string(l) + ".";
+        if ((rc = copy_vec(c, m, p + "input_layernorm.weight", H, &w.ln1, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "post_attention_layernorm.weight", H, &w.ln2, st))) return rc;
+        // fused q|k|v
+        const int nq = QD / 16, nk = KD / 16;
+        if ((rc = alloc_packed(c, &w.qkv, nq + 2 * nk, H))) return rc;
+        w.qkv.N = QD + 2 * KD;
+        if ((rc = pack_into(c, m, p + "self_attn.q_proj.weight", QD, H, &w.qkv, 1, 0, st))) return rc;
+        if ((rc = pack_into(c, m, p + "self_attn.k_proj.weight", KD, H, &w.qkv, 1, nq, st))) return rc;
+        if ((rc = pack_into(c, m, p + "self_attn.v_proj.weight", KD, H, &w.qkv, 1, nq + nk, st))) return rc;
+        if ((rc = dalloc(c, &w.qkv_bias, (size_t)QD + 2 * KD))) return rc;
+        const aha_tensor_view *bq = need(c, m, p + "self_attn.q_proj.bias", 1, QD, 1), *bk = need(c, m, p + "self_attn.k_proj.bias", 1, KD, 1),
+                              *bv = need(c, m, p + "self_attn.v_proj.bias", 1, KD, 1);
+        if (!bq || !bk || !bv) return AHA_E_NOENT;
+        HIPCHK(c, hipMemcpyAsync(w.qkv_bias, bq->data, QD * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(w.qkv_bias + QD, bk->data, KD * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(w.qkv_bias + QD + KD, bv->data, KD * 2, hipMemcpyDeviceToDevice, st));
+        if ((rc = alloc_packed(c, &w.o, H / 16, QD))) return rc;
+        w.o.N = H;
+        if ((rc = pack_into(c, m, p + "self_attn.o_proj.weight", H, QD, &w.o, 1, 0, st))) return rc;
+        // gate/up interleaved by 16-row tiles: tile 2t = gate tile t, tile 2t+1 = up tile t
+        if ((rc = alloc_packed(c, &w.gateup, 2 * (I / 16), H))) return rc;
+        w.gateup.N = I;
+        if ((rc = pack_into(c, m, p + "mlp.gate_proj.weight", I, H, &w.gateup, 2, 0, st))) return rc;
+        if ((rc = pack_into(c, m, p + "mlp.up_proj.weight", I, H, &w.gateup, 2, 1, st))) return rc;
+        if ((rc = alloc_packed(c, &w.down, H / 16, I))) return rc;
+        w.down.N = H;
+        if ((rc = pack_into(c, m, p + "mlp.down_proj.weight", H, I, &w.down, 1, 0, st))) return rc;
+    }
+    if ((rc = copy_vec(c, m, "model.norm.weight", H, &c->final_norm, st))) return rc;
+    if ((rc = dalloc(c, &c->heads_w, (size_t)4 * H))) return rc;
+    {
+        const aha_tensor_view *ti = need(c, m, "informative_head.weight", 2, 2, H), *tr = need(c, m, "relevance_head.weight", 2, 1, H),
+                              *tu = need(c, m, "uncertainty_head.weight", 2, 1, H);
+        if (!ti || !tr || !tu) return AHA_E_NOENT;
+        HIPCHK(c, hipMemcpyAsync(c->heads_w, ti->data, 2 * H * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->heads_w + 2 * H, tr->data, H * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->heads_w + 3 * H, tu->data, H * 2, hipMemcpyDeviceToDevice, st));
+    }
+    if (m.count("model.embed_tokens.weight")) {
+        if ((rc = copy_vec(c, m, "model.embed_tokens.weight", (int64_t)d.vocab * H, &c->embed, st))) return rc;
+    }
+    if (m.count("lm_head.weight")) {
+        if ((rc = alloc_packed(c, &c->lm_head, ceil_div(d.vocab, 16), H))) return rc;
+        c->lm_head.N = d.vocab;
+        if ((rc = pack_into(c, m, "lm_head.weight", d.vocab, H, &c->lm_head, 1, 0, st))) return rc;
+    }
+    // ---- vision
+    const int Dv = d.v_hidden, PP3 = 3 * d.patch_size * d.patch_size;
+    {
+        const aha_tensor_view* t = need(c, m, "vision.embeddings.patch_embedding.weight", 2, Dv, PP3);
+        if (!t) return AHA_E_NOENT;
+        if ((rc = dalloc(c, &c->patch_w, (size_t)Dv * c->Kp))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->patch_w, 0, (size_t)Dv * c->Kp * 2, st));
+        HIPCHK(c, hipMemcpy2DAsync(c->patch_w, (size_t)c->Kp * 2, t->data, (size_t)PP3 * 2, (size_t)PP3 * 2, Dv, hipMemcpyDeviceToDevice, st));
+    }
+    if ((rc = copy_vec(c, m, "vision.embeddings.patch_embedding.bias", Dv, &c->patch_b, st))) return rc;
+    if ((rc = copy_vec(c, m, "vision.embeddings.position_embedding.weight", (int64_t)c->Np * Dv, &c->pos_emb, st))) return rc;
+    c->V.resize(d.v_layers);
+    for (int l = 0; l < d.v_layers; ++l) {
+        VLayerW& w = c->V[l];
+        const std::string p = "vision.encoder.layers." + std::to_string(l) + ".";
+        if ((rc = copy_vec(c, m, p + "layer_norm1.weight", Dv, &w.ln1w, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "layer_norm1.bias", Dv, &w.ln1b, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "layer_norm2.weight", Dv, &w.ln2w, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "layer_norm2.bias", Dv, &w.ln2b, st))) return rc;
+        if ((rc = dalloc(c, &w.wqkv, (size_t)3 * Dv * Dv))) return rc;
+        if ((rc = dalloc(c, &w.bqkv, (size_t)3 * Dv))) return rc;
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            const aha_tensor_view *tw = need(c, m, p + "self_attn." + names[j] + ".weight", 2, Dv, Dv),
+                                  *tb = need(c, m, p + "self_attn." + names[j] + ".bias", 1, Dv, 1);
+            if (!tw || !tb) return AHA_E_NOENT;
+            HIPCHK(c, hipMemcpyAsync(w.wqkv + (size_t)j * Dv * Dv, tw->data, (size_t)Dv * Dv * 2, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(w.bqkv + (size_t)j * Dv, tb->data, (size_t)Dv * 2, hipMemcpyDeviceToDevice, st));
+        }
+        if ((rc = copy_vec(c, m, p + "self_attn.out_proj.weight", (int64_t)Dv * Dv, &w.wo, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "self_attn.out_proj.bias", Dv, &w.bo, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "mlp.fc1.weight", (int64_t)d.v_inter * Dv, &w.w1, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "mlp.fc1.bias", d.v_inter, &w.b1, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "mlp.fc2.weight", (int64_t)Dv * d.v_inter, &w.w2, st))) return rc;
+        if ((rc = copy_vec(c, m, p + "mlp.fc2.bias", Dv, &w.b2, st))) return rc;
+    }
+    if ((rc = copy_vec(c, m, "mm_projector.0.weight", (int64_t)H * Dv, &c->p0w, st))) return rc;
+    if ((rc = copy_vec(c, m, "mm_projector.0.bias", H, &c->p0b, st))) return rc;
+    if ((rc = copy_vec(c, m, "mm_projector.2.weight", (int64_t)H * H, &c->p2w, st))) return rc;
+    if ((rc = copy_vec(c, m, "mm_projector.2.bias", H, &c->p2b, st))) return rc;
+    HIPCHK(c, hipStreamSynchronize(st));      // sources may be freed by the caller after return
+    c->weights_loaded = true;
+    return 0;
+}
+
+extern "C" int aha_ctx_set_rope_table(aha_ctx* c, const void* cosb, const void* sinb, int n_pos, aha_hip_stream st_) {
+    if (!c || !cosb || !sinb || n_pos <= 0) return AHA_E_INVAL;
+    hipStream_t st = (hipStream_t)st_;
+    int rc;
+    const size_t n = (size_t)n_pos * c->d.head_dim;
+    if ((rc = dalloc(c, &c->rope_cos, n))) return rc;
+    if ((rc = dalloc(c, &c->rope_sin, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->rope_cos, cosb, n * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->rope_sin, sinb, n * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->n_pos = n_pos;
+    return 0;
+}
+
+extern "C" int aha_ctx_set_rerotation_table(aha_ctx* c, int window, int n_sink, int T, const void* cosb, const void* sinb,
+                                            aha_hip_stream st_) {
+    if (!c || !cosb || !sinb) return AHA_E_INVAL;
+    const int rows = window - n_sink - T;
+    if (rows <= 0) return fail(c, AHA_E_RANGE, "rerotation table needs window - n_sink - T > 0");
+    hipStream_t st = (hipStream_t)st_;
+    auto key = std::make_tuple(window, n_sink, T);
+    if (c->rerot.count(key)) return 0;
+    bf16 *pc, *ps;
+    int rc;
+    const size_t n = (size_t)rows * c->d.head_dim;
+    if ((rc = dalloc(c, &pc, n))) return rc;
+    if ((rc = dalloc(c, &ps, n))) return rc;
+    HIPCHK(c, hipMemcpyAsync(pc, cosb, n * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ps, sinb, n * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->rerot[key] = {pc, ps};
+    return 0;
+}
+
+extern "C" int aha_ctx_has_rerotation_table(aha_ctx* c, int window, int n_sink, int T) {
+    return c && c->rerot.count(std::make_tuple(window, n_sink, T)) ? 1 : 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// streams
+// --------------------------------------------------------------------------------------------
+extern "C" int aha_stream_open(aha_ctx* c, int policy, int window, int n_sink, int capacity, aha_stream** out) {
+    if (!c || !out) return AHA_E_INVAL;
+    if (policy < AHA_CACHE_NONE || policy > AHA_CACHE_STATIC) return fail(c, AHA_E_INVAL, "bad cache policy");
+    if (policy != AHA_CACHE_NONE && window <= 0) return fail(c, AHA_E_INVAL, "window must be > 0");
+    if (policy == AHA_CACHE_SINK && (n_sink < 0 || n_sink >= window)) return fail(c, AHA_E_INVAL, "bad n_sink");
+    if (policy == AHA_CACHE_NONE && capacity <= 0) return fail(c, AHA_E_INVAL, "capacity must be > 0");
+    aha_stream* s = new aha_stream();
+    s->ctx = c;
+    s->policy = policy;
+    s->W = window;
+    s->sink = policy == AHA_CACHE_SINK ? n_sink : 0;
+    s->cap = policy == AHA_CACHE_NONE ? capacity : window;
+    const size_t n = (size_t)c->d.layers * c->d.kv_heads * s->cap * c->d.head_dim;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&s->k, n * 2) != hipSuccess ||
+        hipMalloc((void**)&s->v, n * 2) != hipSuccess) {
+        if (s->k) hipFree(s->k);
+        delete s;
+        return fail(c, AHA_E_NOMEM, "KV cache allocation failed");
+    }
+    hipMemset(s->k, 0, n * 2);
+    hipMemset(s->v, 0, n * 2);
+    *out = s;
+    return 0;
+}
+extern "C" int aha_stream_reset(aha_stream* s) {
+    if (!s) return AHA_E_INVAL;
+    s->len = s->head = s->seen = 0;
+    return 0;
+}
+extern "C" int aha_stream_seq_length(const aha_stream* s) { return s ? s->len : AHA_E_INVAL; }
+extern "C" int aha_stream_seen_tokens(const aha_stream* s) { return s ? s->seen : AHA_E_INVAL; }
+extern "C" int aha_stream_set_attn_semantics(aha_stream* s, int sem) {
+    if (!s || (sem != AHA_ATTN_TRAILING && sem != AHA_ATTN_HF449_SDPA)) return AHA_E_INVAL;
+    s->semantics = sem;
+    return 0;
+}
+extern "C" void aha_stream_destroy(aha_stream* s) {
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    hipDeviceSynchronize();
+    hipFree(s->k);
+    hipFree(s->v);
+    delete s;
+}
+
+// Advance one stream's bookkeeping by T new tokens and describe the step for the kernels.
+// Follows SinkCache.update (test/sink_cache.py:123-162), SlidingWindowCache.update
+// (test/sliding_window_cache.py:28-44), TrulyStaticCache.update (test/static_cache.py:26-36) and
+// DynamicCache; position rule: positions = get_seq_length() + arange(T).
+static int plan_stream(aha_ctx* c, aha_stream* s, int T, StreamStep* o) {
+    const int L = s->len, W = s->W;
+    memset(o, 0, sizeof(*o));
+    o->k_base = s->k;
+    o->v_base = s->v;
+    o->cap = s->cap;
+    o->pos_base = L;
+    o->ring_cap = 1;
+    o->write_count = T;
+    int new_len = L, new_head = s->head;
+    bool shifted = false;
+    switch (s->policy) {
+        case AHA_CACHE_NONE:
+            if (L + T > s->cap) return fail(c, AHA_E_RANGE, "stream capacity exceeded (AHA_CACHE_NONE)");
+            o->n_fixed = s->cap;
+            o->write_base = L;
+            new_len = L + T;
+            break;
+        case AHA_CACHE_STATIC:
+            o->n_fixed = s->cap;
+            if (L == 0) {
+                o->write_base = 0;
+                o->write_count = T < W ? T : W;
+                new_len = o->write_count;
+            } else {
+                o->write_base = -1;
+                o->write_count = 0;
+            }
+            break;
+        case AHA_CACHE_SLIDING:
+            if (T > W) return fail(c, AHA_E_RANGE, "T > window unsupported (SlidingWindowCache)");
+            o->n_fixed = 0;
+            o->ring_cap = W;
+            if (L + T <= W) {
+                o->write_base = L;
+                new_len = L + T;
+            } else {
+                new_head = (s->head + (L + T - W)) % W;
+                new_len = W;
+                o->write_base = W - T;
+                shifted = true;
+            }
+            break;
+        case AHA_CACHE_SINK: {
+            o->n_fixed = s->sink;
+            o->ring_cap = W - s->sink;
+            if (L == 0 ? T < W : L + T < W) {
+                o->write_base = L;
+                new_len = L + T;
+            } else {
+                if (L == 0) return fail(c, AHA_E_RANGE, "first chunk >= window unsupported (SinkCache)");
+                const int keep = W - s->sink - T;
+                if (keep <= 0 || L < s->sink) return fail(c, AHA_E_RANGE, "T too large for window - n_sink (SinkCache)");
+                new_head = (s->head + (L + T - W)) % o->ring_cap;
+                new_len = W;
+                o->write_base = W - T;
+                o->n_rerot = keep;
+                o->rerot_row0 = 0;
+                shifted = true;
+            }
+            break;
+        }
+    }
+    o->ring_head = new_head;
+    o->len_after = new_len;
+    if (s->policy == AHA_CACHE_STATIC)
+        o->causal_off = (L == 0) ? 0 : (1 << 29);                  // first call: plain causal; frozen: all visible
+    else if (s->semantics == AHA_ATTN_HF449_SDPA)
+        o->causal_off = L;                                         // key j visible iff j <= L_before + t
+    else
+        o->causal_off = new_len - T;                               // trailing T x T block causal
+    (void)shifted;
+    s->len = new_len;
+    s->head = new_head;
+    s->seen += T;
+    return 0;
+}
+
+__global__ void export_kv_kernel(StreamStep ss, int layer, int Hkv, int D, int want_v, int len, bf16* out) {
+    const int j = blockIdx.x, hk = blockIdx.y;
+    const int slot = phys_slot(ss, j);
+    const bf16* src = (want_v ? ss.v_base : ss.k_base) + (((long)layer * Hkv + hk) * ss.cap + slot) * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[((long)hk * len + j) * D + d] = src[d];
+}
+
+extern "C" int aha_stream_export_kv(aha_ctx* c, const aha_stream* s, int layer, int want_v, void* out, aha_hip_stream st) {
+    if (!c || !s || !out) return AHA_E_INVAL;
+    if (s->len == 0) return 0;
+    StreamStep ss;
+    memset(&ss, 0, sizeof(ss));
+    ss.k_base = s->k; ss.v_base = s->v; ss.cap = s->cap; ss.ring_head = s->head;
+    if (s->policy == AHA_CACHE_NONE || s->policy == AHA_CACHE_STATIC) { ss.n_fixed = s->cap; ss.ring_cap = 1; }
+    else if (s->policy == AHA_CACHE_SLIDING) { ss.n_fixed = 0; ss.ring_cap = s->W; }
+    else { ss.n_fixed = s->sink; ss.ring_cap = s->W - s->sink; }
+    hipLaunchKernelGGL(export_kv_kernel, dim3(s->len, c->d.kv_heads), dim3(64), 0, (hipStream_t)st, ss, layer, c->d.kv_heads,
+                       c->d.head_dim, want_v, s->len, (bf16*)out);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// vision
+// --------------------------------------------------------------------------------------------
+static hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ldw, int N, int K, bf16* C, int ldc, const bf16* bias,
+                            int act, const bf16* residual, int ldr, const bf16* rowadd, int period, int ldra, hipStream_t st) {
+    GemmTileArgs g;
+    g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
+    g.residual = residual; g.ldr = ldr; g.rowadd = rowadd; g.rowadd_period = period > 0 ? period : 1; g.ldra = ldra;
+    return aha_gemm_tile(&g, st);
+}
+
+extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* out_embeds, aha_hip_stream st_) {
+    if (!c || !frames || !out_embeds) return AHA_E_INVAL;
+    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
+    if (n <= 0) return 0;
+    if (n > c->d.max_vit_frames) return fail(c, AHA_E_RANGE, "n_frames > max_vit_frames");
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden, vhd = Dv / d.v_heads;
+    HIPCHK(c, aha_im2col_norm(frames, n, d.image_size, d.patch_size, c->Kp, c->v_a0, st));
+    HIPCHK(c, tile_gemm(c->v_a0, c->Kp, rows, c->patch_w, c->Kp, Dv, c->Kp, c->v_x, Dv, c->patch_b, ACT_NONE, nullptr, 0,
+                        c->pos_emb, c->Np, Dv, st));
+    for (int l = 0; l < d.v_layers; ++l) {
+        const VLayerW& w = c->V[l];
+        HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+        AttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.q = c->v_qkv; a.q_bs = (long)c->Np * 3 * Dv; a.ldq = 3 * Dv;
+        a.k = c->v_qkv + Dv; a.v = c->v_qkv + 2 * Dv; a.kv_bs = (long)c->Np * 3 * Dv; a.ldk = 3 * Dv;
+        a.out = c->v_attn; a.o_bs = (long)c->Np * Dv; a.ldo = Dv;
+        a.T = c->Np; a.G = 1; a.Hkv = d.v_heads; a.Lk = c->Np;
+        a.split_len = round_up(c->Np, 64); a.n_splits = 1;
+        a.scale = 1.0f / sqrtf((float)vhd);
+        HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
+        HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
+        HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, d.v_inter, w.b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, tile_gemm(c->v_f, d.v_inter, rows, w.w2, d.v_inter, Dv, d.v_inter, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
+    }
+    HIPCHK(c, tile_gemm(c->v_x, Dv, rows, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
+    HIPCHK(c, tile_gemm(c->v_p1, H, rows, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+    HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, st));
+    return 0;
+}
+
+extern "C" int aha_vit_last_tower_output(aha_ctx* c, int n_frames, void* out, aha_hip_stream st) {
+    if (!c || !out || n_frames <= 0 || n_frames > c->d.max_vit_frames) return AHA_E_INVAL;
+    HIPCHK(c, hipMemcpyAsync(out, c->v_x, (size_t)n_frames * c->Np * c->d.v_hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return 0;
+}
+
+extern "C" int aha_embed_tokens(aha_ctx* c, const int64_t* ids, int n, void* out, aha_hip_stream st) {
+    if (!c || !ids || !out) return AHA_E_INVAL;
+    if (!c->embed) return fail(c, AHA_E_NOENT, "model.embed_tokens.weight was not loaded");
+    HIPCHK(c, aha_embed_gather((const long*)ids, n, c->embed, c->d.hidden, c->d.vocab, (bf16*)out, c->d.hidden, (hipStream_t)st));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// LM step
+// --------------------------------------------------------------------------------------------
+static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave) {
+    const int mt = ceil_div(M < 256 ? M : 256, 16);
+    int kc = nt_per_wave == 1 ? (mt <= 4 ? 8 : mt <= 8 ? 4 : 2) : (mt <= 1 ? 8 : mt <= 4 ? 4 : 2);
+    const int nc = ceil_div(w.KS, kc);
+    int S = c->split[kind];
+    if (S <= 0) {
+        const int nblk = ceil_div(w.n_tiles, 4 * nt_per_wave);
+        S = 512 / (nblk > 0 ? nblk : 1);
+        if (S > 8) S = 8;
+    }
+    if (S > nc) S = nc;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    return S;
+}
+
+static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
+                   bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
+    const int mmax = aha_gemm_ws_max_m(epi);
+    const bool timed = c->time_gemm && kind >= 0;
+    if (timed) {
+        if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
+            hipEvent_t a, b;
+            HIPCHK(c, hipEventCreate(&a));
+            HIPCHK(c, hipEventCreate(&b));
+            c->ev[kind].push_back({a, b});
+        }
+        HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].first, st));
+    }
+    for (int m0 = 0; m0 < M; m0 += mmax) {
+        GemmWsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.X = X + (long)m0 * ldx; a.ldx = ldx; a.M = (M - m0 < mmax) ? M - m0 : mmax;
+        a.Wp = w.p; a.KS = w.KS; a.n_tiles = w.n_tiles; a.S = S;
+        a.partial = partial ? partial + (long)m0 * ldp : nullptr; a.ldp = ldp; a.slab_stride = (long)M * ldp;
+        a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
+        a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;
+        a.bias = nullptr; a.N = w.N;
+        HIPCHK(c, aha_gemm_ws(&a, epi, st));
+    }
+    if (timed) {
+        HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].second, st));
+        c->ev_used[kind]++;
+        c->gk_bytes[kind] += w.bytes() * ceil_div(M, mmax);
+    }
+    c->last_weight_bytes += w.bytes();
+    c->last_flops += 2.0 * (double)w.n_tiles * 16.0 * (double)w.K * (double)M;
+    return 0;
+}
+
+extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
+                           float* out_raw, void* out_last_hidden, aha_hip_stream st_) {
+    if (!c || !streams || !embeds) return AHA_E_INVAL;
+    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
+    if (!c->rope_cos) return fail(c, AHA_E_INVAL, "rope table not set");
+    if (B <= 0 || B > AHA_MAX_B) return fail(c, AHA_E_RANGE, "B out of range (1..16)");
+    if (T <= 0 || B * T > c->d.max_step_tokens) return fail(c, AHA_E_RANGE, "B*T > max_step_tokens");
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int H = d.hidden, Dh = d.head_dim, QD = d.heads * Dh, I = d.inter, M = B * T, G = d.heads / d.kv_heads;
+
+    // ---- plan (host bookkeeping only; validate everything before mutating any stream)
+    for (int b = 0; b < B; ++b) {
+        aha_stream* s = streams[b];
+        if (!s || s->ctx != c) return fail(c, AHA_E_INVAL, "bad stream handle");
+        for (int b2 = 0; b2 < b; ++b2)
+            if (streams[b2] == s) return fail(c, AHA_E_INVAL, "a stream may appear only once per step");
+    }
+    StepDesc sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.B = B;
+    sd.T = T;
+    int saved[AHA_MAX_B][3];
+    for (int b = 0; b < B; ++b) {
+        aha_stream* s = streams[b];
+        saved[b][0] = s->len; saved[b][1] = s->head; saved[b][2] = s->seen;
+        int rc = plan_stream(c, s, T, &sd.s[b]);
+        if (!rc && sd.s[b].pos_base + T > c->n_pos) rc = fail(c, AHA_E_RANGE, "position exceeds the RoPE table");
+        if (!rc && sd.s[b].n_rerot > 0 && !c->rerot.count(std::make_tuple(s->W, s->sink, T)))
+            rc = fail(c, AHA_E_NOENT, "re-rotation table for (window, n_sink, T) not set");
+        if (rc) {                                       // roll back every stream touched so far
+            for (int b2 = 0; b2 <= b; ++b2) { streams[b2]->len = saved[b2][0]; streams[b2]->head = saved[b2][1]; streams[b2]->seen = saved[b2][2]; }
+            return rc;
+        }
+    }
+    c->last_weight_bytes = c->last_kv_bytes = c->last_flops = 0;
+    for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
+
+    // ---- SinkCache re-rotation of kept keys (all layers, one launch per distinct table)
+    int max_lk = 0;
+    for (int b = 0; b < B; ++b) {
+        max_lk = sd.s[b].len_after > max_lk ? sd.s[b].len_after : max_lk;
+        c->last_kv_bytes += (double)sd.s[b].len_after * d.layers * d.kv_heads * Dh * 2 * 2;
+    }
+    {
+        // streams sharing (W, sink) share the table; launch per group
+        bool done[AHA_MAX_B] = {false};
+        for (int b = 0; b < B; ++b) {
+            if (done[b] || sd.s[b].n_rerot == 0) continue;
+            StepDesc g = sd;
+            for (int b2 = 0; b2 < B; ++b2) {
+                const bool same = sd.s[b2].n_rerot > 0 && streams[b2]->W == streams[b]->W && streams[b2]->sink == streams[b]->sink;
+                if (same) done[b2] = true; else g.s[b2].n_rerot = 0;
+            }
+            auto tb = c->rerot[std::make_tuple(streams[b]->W, streams[b]->sink, T)];
+            HIPCHK(c, aha_sink_rerotate(&g, tb.first, tb.second, d.layers, d.kv_heads, Dh, st));
+        }
+    }
+
+    // ---- residual stream <- embeds ; first RMSNorm
+    HIPCHK(c, hipMemcpyAsync(c->h, embeds, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(c, aha_rmsnorm(c->h, H, c->L[0].ln1, c->xn, H, M, H, d.rms_eps, st));
+
+    // attention geometry
+    int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
+    int n_splits = ceil_div(max_lk, split_len);
+    if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
+    if (n_splits < 1) n_splits = 1;
+
+    int rc;
+    for (int l = 0; l < d.layers; ++l) {
+        const LayerW& w = c->L[l];
+        // QKV projection -> split-K slabs
+        const int nq_ld = w.qkv.n_tiles * 16;
+        const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);
+        if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, w.qkv, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
+        QkvFinishArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+        qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+        qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+        HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
+        // attention over the stream caches
+        AttnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.q = c->q_rot; a.q_bs = (long)T * QD; a.ldq = QD;
+        a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
+        a.part_o = c->part_o; a.part_ml = c->part_ml;
+        a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
+        a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
+        HIPCHK(c, aha_attention(&a, &sd, B, Dh, st));
+        // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
+        const int So = pick_split(c, GK_O, w.o, M, 1);
+        if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+        ResidNormArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
+        ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
+        HIPCHK(c, aha_resid_norm(&ra, M, st));
+        // gate/up with fused SwiGLU epilogue
+        if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
+        // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
+        const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
+        if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+        ra.S = Sd;
+        ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
+        HIPCHK(c, aha_resid_norm(&ra, M, st));
+        c->last_flops += 4.0 * T * (double)max_lk * QD * B;
+    }
+    // ---- heads on the last token of every stream
+    if (out_scores || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, out_scores, out_raw, st));
+    if (out_last_hidden)
+        HIPCHK(c, hipMemcpy2DAsync(out_last_hidden, (size_t)H * 2, c->xn + (size_t)(T - 1) * H, (size_t)T * H * 2, (size_t)H * 2, B,
+                                   hipMemcpyDeviceToDevice, st));
+    c->last_B = B;
+    c->last_T = T;
+    return 0;
+}
+
+extern "C" int aha_lm_heads_all(aha_ctx* c, float* out_raw, aha_hip_stream st) {
+    if (!c || !out_raw || c->last_B == 0) return AHA_E_INVAL;
+    HIPCHK(c, aha_heads(c->xn, c->d.hidden, 0, 1, c->last_B * c->last_T, c->heads_w, c->d.hidden, nullptr, out_raw, (hipStream_t)st));
+    return 0;
+}
+
+extern "C" int aha_lm_last_hidden_all(aha_ctx* c, void* out, aha_hip_stream st) {
+    if (!c || !out || c->last_B == 0) return AHA_E_INVAL;
+    HIPCHK(c, hipMemcpyAsync(out, c->xn, (size_t)c->last_B * c->last_T * c->d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return 0;
+}
+
+extern "C" int aha_lm_logits_last(aha_ctx* c, float* logits, int64_t* argmax, aha_hip_stream st_) {
+    if (!c || c->last_B == 0) return AHA_E_INVAL;
+    if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
+    hipStream_t st = (hipStream_t)st_;
+    const int B = c->last_B, T = c->last_T, H = c->d.hidden, V = c->d.vocab;
+    float* lg = logits ? logits : c->logits;
+    // last-token rows are strided by T*H in xn: ldx = T*H makes them the M = B rows of the GEMM
+    int rc = ws_gemm(c, -1, c->xn + (size_t)(T - 1) * H, T * H, B, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, lg, V, st);
+    if (rc) return rc;
+    if (argmax) HIPCHK(c, aha_argmax(lg, V, V, B, (long*)argmax, st));
+    return 0;
+}
+
+extern "C" int aha_lm_last_step_work(aha_ctx* c, double* wb, double* kvb, double* fl) {
+    if (!c) return AHA_E_INVAL;
+    if (wb) *wb = c->last_weight_bytes;
+    if (kvb) *kvb = c->last_kv_bytes;
+    if (fl) *fl = c->last_flops;
+    return 0;
+}
+
+extern "C" int aha_lm_last_gemm_time(aha_ctx* c, int kind, float* ms, int* launches, double* bytes) {
+    if (!c || kind < 0 || kind > GK_COUNT) return AHA_E_INVAL;
+    float total = 0.f;
+    int n = 0;
+    double by = 0;
+    for (int k = 0; k < GK_COUNT; ++k) {
+        if (kind != GK_COUNT && kind != k) continue;
+        for (int i = 0; i < c->ev_used[k]; ++i) {
+            float t = 0.f;
+            HIPCHK(c, hipEventSynchronize(c->ev[k][i].second));
+            HIPCHK(c, hipEventElapsedTime(&t, c->ev[k][i].first, c->ev[k][i].second));
+            total += t;
+            ++n;
+        }
+        by += c->gk_bytes[k];
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = n;
+    if (bytes) *bytes = by;
+    return 0;
+}

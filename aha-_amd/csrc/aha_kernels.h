@@ -1,0 +1,77 @@
+// Argument records and launcher prototypes of the gfx950 kernels (internal, not the C ABI).
+#pragma once
+#include "aha_common.h"
+
+enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SWIGLU = 2, EPI_F32_RBF = 3 };
+
+struct GemmWsArgs {
+    const bf16* X; int ldx; int M;
+    const bf16x8* Wp; int KS;        // k-steps of 32 (K = KS*32)
+    int n_tiles;                     // 16-row tiles of the packed weight (N_pad/16)
+    int S;                           // split-K factor (gridDim.y)
+    float* partial; int ldp; long slab_stride;  // EPI_PARTIAL: slab s at partial + s*slab_stride, rows [M][ldp]
+    bf16* out; int ldo;              // EPI_BF16 / EPI_SWIGLU
+    float* outf; int ldof;           // EPI_F32_RBF
+    const bf16* bias;                // EPI_BF16 optional
+    int N;                           // valid output columns (for store guards)
+};
+
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
+
+struct GemmTileArgs {
+    const bf16* A; int lda; int M;
+    const bf16* W; int ldw; int N;
+    int K;                      // K % 8 == 0
+    bf16* C; int ldc;
+    const bf16* bias;           // [N] or null
+    int act;
+    const bf16* residual; int ldr;   // out = bf16(residual + bf16(lin)); may alias C
+    const bf16* rowadd; int rowadd_period, ldra;  // out = bf16(bf16(lin) + rowadd[m % period]) (position embedding)
+};
+
+struct AttnArgs {
+    const bf16* q; long q_bs; int ldq;
+    const bf16* k; const bf16* v; long kv_bs; int ldk;     // dense mode only
+    bf16* out; long o_bs; int ldo;
+    float* part_o; float* part_ml;
+    int T, G, Hkv, Lk;                                     // Lk: dense mode only
+    int split_len, n_splits;
+    float scale;
+    int layer;                                             // LM mode: cache layer index
+};
+
+struct ResidNormArgs {
+    const float* partial; int S; long slab_stride; int ldp;
+    const bf16* lin_bf16; int ldl;
+    bf16* h; int ldh;
+    const bf16* w; bf16* xn; int ldx;
+    int H; float eps;
+};
+
+struct QkvFinishArgs {
+    const float* partial; int S; long slab_stride; int ldp;
+    const bf16* qkv_bf16; int ldq_in;            // alternative input (bias already added)
+    const bf16* bias;                            // [ (Hq+2Hkv)*D ] (partial path)
+    const bf16* rope_cos; const bf16* rope_sin;  // [n_pos][D]
+    int n_pos;
+    bf16* q_rot; int ldq;
+    int Hq, Hkv, D, layer;
+};
+
+extern "C" {
+int aha_gemm_ws_max_m(int epi);
+hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, hipStream_t st);
+hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, int tile_stride, int tile_off, hipStream_t st);
+hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
+hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd, int B, int head_dim, hipStream_t st);
+hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st);
+hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
+hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st);
+hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D, hipStream_t st);
+hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H, float* scores, float* raw, hipStream_t st);
+hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st);
+hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
+hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st);
+hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
+hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);
+}

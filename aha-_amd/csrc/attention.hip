@@ -1,0 +1,236 @@
+// Attention for both halves of the path, one kernel template:
+//   LM  : T new tokens x G query heads per KV head (GQA) against a stream's KV cache that is
+//         addressed through the ring mapping of StreamStep (no per-step cache copy; the
+//         reference re-allocates and copies the whole cache every step, test/sink_cache.py:134-162).
+//         Visibility rule: key j visible to new token t iff j <= causal_off + t.
+//   ViT : dense non-causal attention over the Np patch tokens of one frame.
+//
+// Structure (gfx950, wave64):  a workgroup = 4 waves owns one (kv head, 64-row group, key split);
+// each wave owns ONE 16-row query tile.  Per 64-key block the workgroup stages K (row-major,
+// 16-B chunks XOR-swizzled => conflict-free ds_read_b128) and V (transposed, padded) in LDS, then
+// each wave computes  S^T = K * Q^T  with v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows kept
+// in registers), so a lane holds scores of ONE query row (lane&15) for 4 consecutive keys per
+// key tile: the softmax row reduction is in-register + two xor-shuffles (16, 32), and the
+// exponentiated tile, packed to bf16, IS the B operand of  O^T += V^T * P^T  with no LDS round
+// trip (the k-slot permutation is absorbed by reading V^T as two 8-byte halves).
+// Online softmax in fp32; P rounded to bf16 before PV (flash/sdpa semantics).  With more than
+// one key split the kernel writes (m, l, unnormalised O) partials and attn_combine merges them.
+#include "aha_kernels.h"
+
+
+template <int D> struct AttnCfg {
+    static constexpr int CPR = D / 8;          // 16-B chunks per K row
+    static constexpr int VST = 68;             // V^T row stride in elements (64 keys + 4 pad)
+    static constexpr int DT = D / 16;          // d-tiles of the output
+    static constexpr int KSQ = D / 32;         // k-steps of the QK^T product
+};
+
+template <int D, bool LM>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) bf16 Vt[D * C::VST];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int b = blockIdx.z;
+    const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
+    const int hk = blockIdx.y / RG, rg = blockIdx.y % RG;
+    const int split = blockIdx.x;
+
+    int Lk, off;
+    const bf16 *kb, *vb;
+    int ldk;
+    StreamStep ss;
+    if constexpr (LM) {
+        ss = sd.s[b];
+        Lk = ss.len_after;
+        off = ss.causal_off;
+        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
+        kb = ss.k_base + lo;
+        vb = ss.v_base + lo;
+        ldk = D;
+    } else {
+        Lk = a.Lk;
+        off = 1 << 30;
+        kb = a.k + b * a.kv_bs + hk * D;
+        vb = a.v + b * a.kv_bs + hk * D;
+        ldk = a.ldk;
+    }
+    const int j0 = split * a.split_len;
+    const int j1 = min(Lk, j0 + a.split_len);
+    if (j0 >= j1) return;                                   // uniform per block
+
+    const int rt = rg * 4 + wave;
+    const bool wave_on = rt < RT;
+    int r = rt * 16 + r16;
+    const bool row_ok = wave_on && r < R;
+    if (r > R - 1) r = R - 1;
+    const int g = r / a.T, t = r % a.T;
+    const int head = hk * a.G + g;
+
+    // Q fragments (B operand): Q[row][ks*32 + 8*q4 .. +7]
+    bf16x8 qf[C::KSQ];
+    {
+        const bf16* qp = a.q + b * a.q_bs + (long)t * a.ldq + head * D + q4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < C::KSQ; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+    }
+
+    f32x4 o[C::DT];
+#pragma unroll
+    for (int i = 0; i < C::DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int jb = j0; jb < j1; jb += 64) {
+        __syncthreads();                                    // previous block's LDS reads done
+        // ---- stage K (swizzled rows) and V (transposed) for keys jb .. jb+63
+#pragma unroll
+        for (int i = 0; i < (64 * C::CPR) / 256; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            int j = jb + row; if (j > j1 - 1) j = j1 - 1;  // clamp: finite data, masked below
+            int slot = j;
+            if constexpr (LM) slot = phys_slot(ss, j);
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (long)slot * ldk + ch * 8);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (long)slot * ldk + ch * 8);
+            *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * C::VST + row] = vv[e];
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+
+        // ---- S^T tiles: acc[kt][e] = score(key jb + kt*16 + 4*q4 + e, row r)
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = kt * 16 + r16;
+#pragma unroll
+            for (int ks = 0; ks < C::KSQ; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(
+                    &Ks[row * D + (((ks * 4 + q4) ^ (row & (C::CPR - 1))) << 3)]);
+                s[kt] = mfma16(kf, qf[ks], s[kt]);
+            }
+        }
+        // ---- mask, scale, block max
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = jb + kt * 16 + 4 * q4 + e;
+                const bool vis = (j < j1) && (j <= off + t);
+                const float x = vis ? s[kt][e] * a.scale : -INFINITY;
+                s[kt][e] = x;
+                bmax = fmaxf(bmax, x);
+            }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        const float m_new = fmaxf(m_run, bmax);
+        float alpha = 1.f, psum = 0.f;
+        bf16x8 pb[2];
+        if (m_new == -INFINITY) {                            // nothing visible yet for this row
+            pb[0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            pb[1] = pb[0];
+        } else {
+            alpha = __expf(m_run - m_new);                   // m_run = -inf -> 0
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __expf(s[kt][e] - m_new);  // masked -> exp(-inf) = 0
+                    psum += p;
+                    pb[kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                }
+        }
+        m_run = m_new;
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < C::DT; ++i) o[i] *= alpha;
+        // ---- O^T += V^T * P^T ; k-slot (q4, e): e<4 -> key (2kp)*16+4q4+e, e>=4 -> key (2kp+1)*16+4q4+e-4
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            const int drow = dt * 16 + r16;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(&Vt[drow * C::VST + (2 * kp) * 16 + 4 * q4]);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(&Vt[drow * C::VST + (2 * kp + 1) * 16 + 4 * q4]);
+                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = mfma16(vf, pb[kp], o[dt]);
+            }
+        }
+    }
+    if (!wave_on) return;
+    // row sum across the 4 lanes that share this query row
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (!row_ok) return;
+
+    // o[dt][e] <-> d = dt*16 + 4*q4 + e of row r
+    if (a.n_splits == 1) {
+        const float inv = 1.0f / l_run;
+        bf16* op = a.out + b * a.o_bs + (long)t * a.ldo + head * D + 4 * q4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 ov = {f2bf(o[dt][0] * inv), f2bf(o[dt][1] * inv), f2bf(o[dt][2] * inv), f2bf(o[dt][3] * inv)};
+            *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+        }
+    } else {
+        const int Rpad = RT * 16;
+        const long prow = (((long)b * a.Hkv + hk) * a.n_splits + split) * Rpad + (rt * 16 + r16);
+        float* po = a.part_o + prow * D + 4 * q4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16) = o[dt];
+        if (q4 == 0) {
+            a.part_ml[prow * 2] = m_run;
+            a.part_ml[prow * 2 + 1] = l_run;
+        }
+    }
+}
+
+// Merge key splits: one block of D threads per (b, kv head, row).
+template <int D>
+__global__ void attn_combine_kernel(AttnArgs a, StepDesc sd) {
+    const int R = a.G * a.T, RT = ceil_div(R, 16), Rpad = RT * 16;
+    const int r = blockIdx.x, hk = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
+    const int Lk = sd.s[b].len_after;
+    const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
+    const long base = ((long)b * a.Hkv + hk) * a.n_splits;
+    float M = -INFINITY;
+    for (int s = 0; s < ns; ++s) M = fmaxf(M, a.part_ml[((base + s) * Rpad + r) * 2]);
+    float acc = 0.f, L = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const long prow = (base + s) * Rpad + r;
+        const float w = __expf(a.part_ml[prow * 2] - M);
+        L += w * a.part_ml[prow * 2 + 1];
+        acc += w * a.part_o[prow * D + d];
+    }
+    const int g = r / a.T, t = r % a.T;
+    a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d] = f2bf(acc / L);
+}
+
+template <int D>
+static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipStream_t st) {
+    const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
+    dim3 grid(a.n_splits, a.Hkv * RG, B);
+    if (sd) {
+        hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, st, a, *sd);
+        if (a.n_splits > 1)
+            hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, *sd);
+    } else {
+        StepDesc dummy;
+        dummy.B = B; dummy.T = a.T;
+        hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, st, a, dummy);
+    }
+    return hipGetLastError();
+}
+
+// sd == nullptr: dense (ViT) mode, requires n_splits == 1.
+extern "C" hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
+    if (!sd && a->n_splits != 1) return hipErrorInvalidValue;
+    if (head_dim == 64) return launch_attn<64>(*a, sd, B, st);
+    if (head_dim == 128) return launch_attn<128>(*a, sd, B, st);
+    return hipErrorInvalidValue;
+}

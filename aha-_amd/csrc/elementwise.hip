@@ -1,0 +1,479 @@
+// HBM/L2-bound glue kernels of the streaming path.  All bf16 traffic is 16-B (bf16x8) or 8-B
+// vectors; reductions are wave shuffles + one LDS hop.  Rounding points mirror what the torch
+// ops of the reference produce in bf16 (see oracle/qwen2_live.py, oracle/vision_tower.py).
+#include "aha_kernels.h"
+
+static __device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (modeling_qwen2.py:247-251): fp32 mean of squares, x*rsqrt -> bf16, times bf16 weight.
+// One 256-thread block per row; H % 8 == 0, H <= 8192.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
+                                                      bf16* __restrict__ out, int ldo, int H, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, nch = H >> 3;
+    bf16x8 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            v[i] = *reinterpret_cast<const bf16x8*>(x + (long)row * ldx + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = bf2f(v[i][e]); ss += f * f; }
+        }
+    }
+    ss = block_sum_256(ss, red);
+    const float rstd = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(v[i][e]) * rstd));
+            *reinterpret_cast<bf16x8*>(out + (long)row * ldo + c * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K reduce + residual add + RMSNorm, fused (prologue of the next GEMM):
+//   lin = bf16(sum_s partial[s][row][:])          (the Linear's bf16 output)
+//   h   = bf16(h + lin)                            (residual stream, updated in place)
+//   xn  = w * bf16(h * rsqrt(mean(h^2) + eps))     (next RMSNorm)
+// lin_bf16 != null replaces the slab sum (tiled-GEMM fallback path).
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, nch = a.H >> 3;
+    float hv[4][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            float lin[8];
+            if (a.partial) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lin[e] = 0.f;
+                for (int s = 0; s < a.S; ++s) {
+                    const float* p = a.partial + s * a.slab_stride + (long)row * a.ldp + c * 8;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lin[e] += p0[e]; lin[4 + e] += p1[e]; }
+                }
+            } else {
+                const bf16x8 lv = *reinterpret_cast<const bf16x8*>(a.lin_bf16 + (long)row * a.ldl + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lin[e] = bf2f(lv[e]);
+            }
+            const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
+            bf16x8 ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = rbf(bf2f(hh[e]) + rbf(lin[e]));
+                hv[i][e] = f;
+                ho[e] = f2bf(f);
+                ss += f * f;
+            }
+            *reinterpret_cast<bf16x8*>(a.h + (long)row * a.ldh + c * 8) = ho;
+        }
+    }
+    ss = block_sum_256(ss, red);
+    const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(hv[i][e] * rstd));
+            *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QKV finish: split-K reduce + bias -> bf16 q,k,v ; RoPE on q,k (modeling_qwen2.py:107-131, bf16
+// cos/sin table) ; q -> q_rot[M][Hq*D] ; k,v -> the stream's cache slots.  One block per row.
+// Columns of the fused QKV GEMM: [ q: Hq*D | k: Hkv*D | v: Hkv*D ].
+// ---------------------------------------------------------------------------------------------
+
+template <int D>
+__global__ __launch_bounds__(256) void qkv_finish_kernel(QkvFinishArgs a, StepDesc sd) {
+    constexpr int HALF = D / 2, IPH = HALF / 4;           // items (4 rotation pairs) per head
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int b = row / sd.T, t = row % sd.T;
+    const StreamStep ss = sd.s[b];
+    int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
+    const bool store_kv = ss.write_base >= 0 && t < ss.write_count;
+    int slot = 0;
+    if (store_kv) slot = phys_slot(ss, ss.write_base + t);
+    const int qk_items = (a.Hq + a.Hkv) * IPH;
+    const int v_items = a.Hkv * (D / 4);
+
+    auto fetch4 = [&](int col, float (&o)[4]) {
+        if (a.partial) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.S; ++s)
+                acc += *reinterpret_cast<const f32x4*>(a.partial + s * a.slab_stride + (long)row * a.ldp + col);
+            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rbf(acc[e] + bf2f(bv[e]));
+        } else {
+            const bf16x4 xv = *reinterpret_cast<const bf16x4*>(a.qkv_bf16 + (long)row * a.ldq_in + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bf2f(xv[e]);
+        }
+    };
+
+    for (int it = tid; it < qk_items + v_items; it += 256) {
+        if (it < qk_items) {
+            const int head = it / IPH, d = (it % IPH) * 4;     // head < Hq: query head, else key head
+            const int col = head * D + d;
+            float x1[4], x2[4];
+            fetch4(col, x1);
+            fetch4(col + HALF, x2);
+            const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + d);
+            const bf16x4 s1 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + d);
+            const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + d + HALF);
+            const bf16x4 s2 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + d + HALF);
+            bf16x4 o1, o2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // q*cos + rotate_half(q)*sin, each product and the sum rounded to bf16
+                o1[e] = f2bf(rbf(x1[e] * bf2f(c1[e])) + rbf(-x2[e] * bf2f(s1[e])));
+                o2[e] = f2bf(rbf(x2[e] * bf2f(c2[e])) + rbf(x1[e] * bf2f(s2[e])));
+            }
+            if (head < a.Hq) {
+                bf16* qp = a.q_rot + (long)row * a.ldq + head * D + d;
+                *reinterpret_cast<bf16x4*>(qp) = o1;
+                *reinterpret_cast<bf16x4*>(qp + HALF) = o2;
+            } else if (store_kv) {
+                const int hk = head - a.Hq;
+                bf16* kp = ss.k_base + (((long)a.layer * a.Hkv + hk) * ss.cap + slot) * D + d;
+                *reinterpret_cast<bf16x4*>(kp) = o1;
+                *reinterpret_cast<bf16x4*>(kp + HALF) = o2;
+            }
+        } else if (store_kv) {
+            const int iv = it - qk_items;
+            const int hk = iv / (D / 4), d = (iv % (D / 4)) * 4;
+            float x[4];
+            fetch4((a.Hq + a.Hkv) * D + hk * D + d, x);
+            bf16x4 o = {f2bf(x[0]), f2bf(x[1]), f2bf(x[2]), f2bf(x[3])};
+            *reinterpret_cast<bf16x4*>(ss.v_base + (((long)a.layer * a.Hkv + hk) * ss.cap + slot) * D + d) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SinkCache re-rotation of the kept window keys, in place (test/sink_cache.py:27-33,139-150):
+//   k' = bf16( bf16(k*cos_r) + bf16(rotate_half(k)*sin_r) ), table row = rerot_row0 + kept index.
+// In the ring layout kept keys do not move, so this is the ONLY per-step traffic on old keys.
+// grid: (key blocks, layers*Hkv, B); block 256 threads = (256 / (D/8)) keys x D/8 items.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void sink_rerotate_kernel(StepDesc sd, const bf16* __restrict__ rcos,
+                                                            const bf16* __restrict__ rsin, int layers, int Hkv) {
+    constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
+    const int b = blockIdx.z;
+    const StreamStep ss = sd.s[b];
+    const int key = blockIdx.x * KPB + threadIdx.x / IPK;
+    if (key >= ss.n_rerot) return;
+    const int d = (threadIdx.x % IPK) * 4;
+    const int slot = phys_slot(ss, ss.n_fixed + key);
+    bf16* kp = ss.k_base + ((long)blockIdx.y * ss.cap + slot) * D + d;     // blockIdx.y = layer*Hkv + hk
+    const long trow = (long)(ss.rerot_row0 + key) * D;
+    const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
+    const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d), s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
+    const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF), s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a1 = bf2f(x1[e]), a2 = bf2f(x2[e]);
+        o1[e] = f2bf(rbf(a1 * bf2f(c1[e])) + rbf(-a2 * bf2f(s1[e])));
+        o2[e] = f2bf(rbf(a2 * bf2f(c2[e])) + rbf(a1 * bf2f(s2[e])));
+    }
+    *reinterpret_cast<bf16x4*>(kp) = o1;
+    *reinterpret_cast<bf16x4*>(kp + HALF) = o2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The three scoring heads on final-normed hidden rows (video_head_live_llava_qwen.py:185-188) and
+// the score post-ops of _encode_frame (test/inference.py:222-227).  heads_w = [info0; info1; rel; unc]
+// rows of H.  Row i of the launch reads hidden row (row_first + i*row_step).
+//   raw[i]    = bf16-rounded logits (info0, info1, rel_logit, log_var)
+//   scores[i] = (softmax(info)[1], sigmoid(rel), exp(log_var))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void heads_kernel(const bf16* __restrict__ xn, int ldx, int row_first, int row_step,
+                                                    const bf16* __restrict__ heads_w, int H, float* __restrict__ scores,
+                                                    float* __restrict__ raw) {
+    __shared__ float red[4][4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16* x = xn + (long)(row_first + i * row_step) * ldx;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = tid; c < (H >> 3); c += 256) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + c * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(heads_w + (long)k * H + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[k] += bf2f(xv[e]) * bf2f(wv[e]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave][k] = acc[k];
+    __syncthreads();
+    if (tid == 0) {
+        float l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l[k] = rbf(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        if (raw) { raw[i * 4 + 0] = l[0]; raw[i * 4 + 1] = l[1]; raw[i * 4 + 2] = l[2]; raw[i * 4 + 3] = l[3]; }
+        if (scores) {
+            const float m = fmaxf(l[0], l[1]);
+            const float e0 = expf(l[0] - m), e1 = expf(l[1] - m);
+            scores[i * 3 + 0] = e1 / (e0 + e1);
+            scores[i * 3 + 1] = 1.0f / (1.0f + expf(-l[2]));
+            scores[i * 3 + 2] = expf(l[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vision glue
+// ---------------------------------------------------------------------------------------------
+// uint8 frames [N,3,S,S] -> normalised bf16 im2col rows [N*Np][Kp], column = c*P*P + iy*P + ix,
+// value = bf16((u8/255 - .5)/.5)  (preprocess fused into the patch gather; vision_live.py:11-13)
+__global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, int S, int P, int grid, int Kp,
+                                   bf16* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kch = Kp >> 3;
+    const long total = (long)N * grid * grid * kch;
+    if (gid >= total) return;
+    const int kc = (int)(gid % kch);
+    const long rowi = gid / kch;
+    const int px = (int)(rowi % grid), py = (int)((rowi / grid) % grid), n = (int)(rowi / ((long)grid * grid));
+    const int PP = P * P, K = 3 * PP;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kc * 8 + e;
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / PP, rem = k % PP, iy = rem / P, ix = rem % P;
+            const uint8_t u = frames[(((long)n * 3 + c) * S + (py * P + iy)) * S + (px * P + ix)];
+            v = ((float)u * 0.00392156862745098f - 0.5f) / 0.5f;
+        }
+        o[e] = f2bf(v);
+    }
+    *reinterpret_cast<bf16x8*>(out + rowi * Kp + kc * 8) = o;
+}
+
+// LayerNorm over the last dim, one wave per row (4 rows per block); D % 8 == 0, D <= 4096.
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
+                                                        const bf16* __restrict__ bias, bf16* __restrict__ out, int ldo,
+                                                        int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nch = D >> 3;
+    bf16x8 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            v[i] = *reinterpret_cast<const bf16x8*>(x + (long)row * ldx + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += bf2f(v[i][e]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dlt = bf2f(v[i][e]) - mean; vs += dlt * dlt; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(vs) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(bias + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf((bf2f(v[i][e]) - mean) * rstd * bf2f(wv[e]) + bf2f(bv[e]));
+            *reinterpret_cast<bf16x8*>(out + (long)row * ldo + c * 8) = o;
+        }
+    }
+}
+
+// post_projector_pooling (video_head_live_llava_qwen.py:117-136): [N, g, g, H] -> [N, go, go, H].
+// mode 0 = bilinear (align_corners=False), 1 = average (stride x stride), 2 = max.
+__global__ void pool_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int g, int go, int H,
+                            int stride, int mode) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int hch = H >> 3;
+    const long total = (long)N * go * go * hch;
+    if (gid >= total) return;
+    const int hc = (int)(gid % hch);
+    const long cell = gid / hch;
+    const int ox = (int)(cell % go), oy = (int)((cell / go) % go), n = (int)(cell / ((long)go * go));
+    const bf16* base = in + (long)n * g * g * H + hc * 8;
+    float acc[8];
+    if (mode == 0) {
+        const float sc = (float)g / (float)go;
+        float sy = sc * ((float)oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+        float sx = sc * ((float)ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < g - 1 ? 1 : 0), x1 = x0 + (x0 < g - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(base + ((long)y0 * g + x0) * H);
+        const bf16x8 v01 = *reinterpret_cast<const bf16x8*>(base + ((long)y0 * g + x1) * H);
+        const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(base + ((long)y1 * g + x0) * H);
+        const bf16x8 v11 = *reinterpret_cast<const bf16x8*>(base + ((long)y1 * g + x1) * H);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            acc[e] = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (mode == 1) ? 0.f : -INFINITY;
+        for (int dy = 0; dy < stride; ++dy)
+            for (int dx = 0; dx < stride; ++dx) {
+                const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + ((long)(oy * stride + dy) * g + (ox * stride + dx)) * H);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = (mode == 1) ? acc[e] + bf2f(vv[e]) : fmaxf(acc[e], bf2f(vv[e]));
+            }
+        if (mode == 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] /= (float)(stride * stride);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    *reinterpret_cast<bf16x8*>(out + cell * H + hc * 8) = o;
+}
+
+// Token embedding gather: out[i][:] = table[ids[i]][:]
+__global__ void embed_gather_kernel(const long* __restrict__ ids, int n, const bf16* __restrict__ table, int H, int vocab,
+                                    bf16* __restrict__ out, int ldo) {
+    const int i = blockIdx.x;
+    long id = ids[i]; if (id < 0) id = 0; if (id > vocab - 1) id = vocab - 1;
+    for (int c = threadIdx.x; c < (H >> 3); c += blockDim.x)
+        *reinterpret_cast<bf16x8*>(out + (long)i * ldo + c * 8) = *reinterpret_cast<const bf16x8*>(table + id * H + c * 8);
+}
+
+// argmax over fp32 logits rows (first maximal index, like torch.argmax)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V, long* __restrict__ out) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float best = -INFINITY; int idx = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        const float v = logits[(long)row * ld + c];
+        if (v > best || (v == best && c < idx)) { best = v; idx = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[row] = idx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    if ((H & 7) || H > 8192) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(256), 0, st, x, ldx, w, out, ldo, H, eps);
+    return hipGetLastError();
+}
+hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    if ((a->H & 7) || a->H > 8192) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resid_norm_kernel, dim3(M), dim3(256), 0, st, *a);
+    return hipGetLastError();
+}
+hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st) {
+    const int M = sd->B * sd->T;
+    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M), dim3(256), 0, st, *a, *sd);
+    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M), dim3(256), 0, st, *a, *sd);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D,
+                             hipStream_t st) {
+    int nmax = 0;
+    for (int b = 0; b < sd->B; ++b) nmax = sd->s[b].n_rerot > nmax ? sd->s[b].n_rerot : nmax;
+    if (nmax == 0) return hipSuccess;
+    if (D == 64) {
+        const int kpb = 256 / (64 / 8);
+        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, sd->B), dim3(256), 0, st, *sd, rcos, rsin, layers, Hkv);
+    } else if (D == 128) {
+        const int kpb = 256 / (128 / 8);
+        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, sd->B), dim3(256), 0, st, *sd, rcos, rsin, layers, Hkv);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H,
+                     float* scores, float* raw, hipStream_t st) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(256), 0, st, xn, ldx, row_first, row_step, heads_w, H, scores, raw);
+    return hipGetLastError();
+}
+hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st) {
+    const int grid = S / P;
+    const long total = (long)N * grid * grid * (Kp >> 3);
+    hipLaunchKernelGGL(im2col_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, N, S, P, grid, Kp, out);
+    return hipGetLastError();
+}
+hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
+                         hipStream_t st) {
+    if ((D & 7) || D > 4096) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, x, ldx, w, b, out, ldo, M, D, eps);
+    return hipGetLastError();
+}
+hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st) {
+    const long total = (long)N * go * go * (H >> 3);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, N, g, go, H, stride, mode);
+    return hipGetLastError();
+}
+hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(256), 0, st, ids, n, table, H, vocab, out, ldo);
+    return hipGetLastError();
+}
+hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, logits, ld, V, out);
+    return hipGetLastError();
+}
+}

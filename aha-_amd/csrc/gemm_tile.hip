@@ -1,0 +1,155 @@
+// Tiled MFMA GEMM for the vision tower / projector (M = frames*patches is large, MFMA-bound):
+//     C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias )
+// 128x128 output tile, BK = 64, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64
+// (4x4 v_mfma_f32_16x16x32_bf16 accumulators).  Operands are staged global -> registers -> LDS
+// (issue-early / write-late: the loads of tile k+1 are in flight during the MFMAs of tile k),
+// LDS rows are 128 B with the 16-B chunk index XOR-swizzled by (row & 7) so both the staging
+// ds_write_b128 and the fragment ds_read_b128 are bank-conflict free.  MFMA A operand = W rows,
+// B operand = activation rows, so each lane's accumulator holds 4 consecutive n of one m and the
+// epilogue stores 8-byte bf16x4 vectors.  Block ids are remapped so that the blocks one XCD
+// receives (ids equal mod 8) walk consecutive n-tiles of the same m-panel (A panel stays in
+// that XCD's L2).
+#include "aha_kernels.h"
+
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+
+static __device__ __forceinline__ float gelu_tanh_f(float x) {
+    // torch gelu(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+    const float k = 0.7978845608028654f;
+    const float inner = k * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+static __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16 As[2][TBM * TBK];
+    __shared__ __attribute__((aligned(16))) bf16 Ws[2][TBN * TBK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap (bijective only when nblk % 8 == 0; otherwise identity)
+    const int tiles_n = ceil_div(g.N, TBN), tiles_m = ceil_div(g.M, TBM);
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int bm = bid / tiles_n, bn = bid % tiles_n;
+    const int m0 = bm * TBM, n0 = bn * TBN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: each thread moves 4 chunks of A and 4 of W per k-tile: row = tid/8 + 32*i, chunk = tid%8
+    const int srow = tid >> 3, sch = tid & 7;
+    bf16x8 ra[4], rw[4];
+    auto gload = [&](int kt) {
+        const int k = kt * TBK + sch * 8;
+        const bool kok = k < g.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int am = m0 + srow + 32 * i; if (am > g.M - 1) am = g.M - 1;
+            int wn_ = n0 + srow + 32 * i; if (wn_ > g.N - 1) wn_ = g.N - 1;
+            if (kok) {
+                ra[i] = *reinterpret_cast<const bf16x8*>(g.A + (long)am * g.lda + k);
+                rw[i] = *reinterpret_cast<const bf16x8*>(g.W + (long)wn_ * g.ldw + k);
+            } else {
+                ra[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                rw[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            const int off = row * TBK + ((sch ^ (row & 7)) << 3);
+            *reinterpret_cast<bf16x8*>(&As[buf][off]) = ra[i];
+            *reinterpret_cast<bf16x8*>(&Ws[buf][off]) = rw[i];
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < TBK / 32; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + r16;
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
+                const int wrow = wn * 64 + i * 16 + r16;
+                wf[i] = *reinterpret_cast<const bf16x8*>(&Ws[buf][wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+        }
+    };
+
+    const int nk = ceil_div(g.K, TBK);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        compute(buf);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][e] <-> m = m0 + wm*64 + i*16 + r16, n = n0 + wn*64 + j*16 + q*4 + e
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r16;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + q * 4;
+            if (n >= g.N) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[i][j][e];
+                if (g.bias && n + e < g.N) x += bf2f(g.bias[n + e]);
+                x = rbf(x);                                   // Linear output (bf16)
+                if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
+                else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                v[e] = x;
+            }
+            if (g.residual) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) v[e] = bf2f(g.residual[(long)m * g.ldr + n + e]) + v[e];
+            }
+            if (g.rowadd) {
+                const int pr = m % g.rowadd_period;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) v[e] = v[e] + bf2f(g.rowadd[(long)pr * g.ldra + n + e]);
+            }
+            if (n + 3 < g.N) {
+                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < g.N) g.C[(long)m * g.ldc + n + e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
+    if (g->M <= 0 || g->N <= 0) return hipSuccess;
+    if ((g->K & 7) || (g->lda & 7) || (g->ldw & 7)) return hipErrorInvalidValue;
+    const int nblk = ceil_div(g->N, TBN) * ceil_div(g->M, TBM);
+    hipLaunchKernelGGL(gemm_tile_kernel, dim3(nblk), dim3(256), 0, st, *g);
+    return hipGetLastError();
+}

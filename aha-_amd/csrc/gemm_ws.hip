@@ -1,0 +1,276 @@
+// Weight-streaming skinny GEMM for the LM step:  Y[M,N] = X[M,K] * W[N,K]^T,  M = B*T <= 256.
+//
+// This is the kernel the LM step's HBM roofline is about (13.05 GB of decoder
+// weights streamed once per step and shared by the B streams).  Design for gfx950:
+//   * W is repacked ONCE at load into MFMA-fragment order  Wp[n_tile][k_step][lane][8 bf16]
+//     (element W[nt*16 + (lane&15)][ks*32 + 8*(lane>>4) + j]), so a wave's weight stream for its
+//     n-tile is a linear sequence of 1 KiB wave-loads (16 B/lane, perfectly coalesced, each byte
+//     read exactly once) that goes straight to VGPRs as the MFMA A operand - no LDS round trip
+//     for the operand that is streamed once (guide: "GEMV / M<=16 decode weights" row).
+//   * X (M x K, L2-resident, re-read by every workgroup) goes through LDS in full rows
+//     (coalesced 16-B loads, padded row stride => conflict-free ds_read_b128 B-fragments).
+//   * v_mfma_f32_16x16x32_bf16 with A = W fragment, B = X^T fragment: the accumulator holds
+//     4 consecutive n for one m per lane => 16-B (fp32) / 8-B (bf16) vector epilogue stores.
+//   * K is split across blockIdx.y (split-K) so every CU streams; partial sums go to fp32 slabs
+//     that the NEXT kernel's prologue reduces (qkv_finish / resid_norm) - no extra launch, no
+//     atomics, bitwise reproducible.
+//   * Software pipeline: weights for chunk c+1 are in flight in a second register set while
+//     chunk c computes; X for chunk c+1 is loaded before them (vmcnt is in-order) and written to
+//     the other LDS buffer after the compute.  One barrier per chunk.
+#include "aha_kernels.h"
+
+
+template <int MT, int NT, int KC>
+struct WsCfg {
+    static constexpr int MPAD = MT * 16;
+    static constexpr int STRIDE = KC * 32 + 8;                 // bf16 elements per LDS row
+    static constexpr int BUF = MPAD * STRIDE;                  // elements per buffer
+    static constexpr int LDS_BYTES = 2 * BUF * 2;
+    static constexpr int XCH = MPAD * KC * 4;                  // 16-B chunks per X chunk tile
+    static constexpr int XLD = (XCH + 255) / 256;              // staging loads per thread
+};
+
+template <int MT, int NT, int KC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmWsArgs a) {
+    using C = WsCfg<MT, NT, KC>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* xs = reinterpret_cast<bf16*>(smem_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int tile0 = (blockIdx.x * 4 + wave) * NT;            // first n-tile of this wave
+    const bool wave_active = tile0 < a.n_tiles;
+    const int NC = (a.KS + KC - 1) / KC;                       // chunks over the whole K
+    const int c0 = (int)(((long)blockIdx.y * NC) / a.S), c1 = (int)(((long)(blockIdx.y + 1) * NC) / a.S);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 wA[KC][NT], wB[KC][NT];
+    bf16x8 xr[C::XLD];
+
+    auto load_w = [&](bf16x8 (&w)[KC][NT], int c) {
+        const int ks0 = c * KC;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int ks = ks0 + i, t = tile0 + j;
+                if (wave_active && ks < a.KS && t < a.n_tiles)
+                    w[i][j] = __builtin_nontemporal_load(&a.Wp[((long)t * a.KS + ks) * 64 + lane]);
+                else
+                    w[i][j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    auto stage_load = [&](int c) {
+        const int kbase = c * KC * 32;
+#pragma unroll
+        for (int i = 0; i < C::XLD; ++i) {
+            const int idx = tid + i * 256;
+            int row = idx / (KC * 4), cc = idx % (KC * 4);
+            if (row > a.M - 1) row = a.M - 1;                   // padded rows: finite duplicates, never stored
+            const int k = kbase + cc * 8;
+            if (idx < C::XCH && k < a.KS * 32)
+                xr[i] = *reinterpret_cast<const bf16x8*>(a.X + (long)row * a.ldx + k);
+            else
+                xr[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::XLD; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / (KC * 4), cc = idx % (KC * 4);
+            if (idx < C::XCH)
+                *reinterpret_cast<bf16x8*>(xs + buf * C::BUF + row * C::STRIDE + cc * 8) = xr[i];
+        }
+    };
+    auto compute = [&](bf16x8 (&w)[KC][NT], int buf) {
+        const bf16* xb = xs + buf * C::BUF + r16 * C::STRIDE + q * 8;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + m * 16 * C::STRIDE + i * 32);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[m][j] = mfma16(w[i][j], xf, acc[m][j]);
+            }
+        }
+    };
+
+    if (c0 < c1) {
+        stage_load(c0);
+        load_w(wA, c0);
+        stage_store(0);
+        __syncthreads();
+        for (int c = c0; c < c1; c += 2) {
+            const bool n1 = (c + 1) < c1;
+            if (n1) { stage_load(c + 1); load_w(wB, c + 1); }
+            compute(wA, 0);
+            if (n1) stage_store(1);
+            __syncthreads();
+            if (!n1) break;
+            const bool n2 = (c + 2) < c1;
+            if (n2) { stage_load(c + 2); load_w(wA, c + 2); }
+            compute(wB, 1);
+            if (n2) stage_store(0);
+            __syncthreads();
+        }
+    }
+    if (!wave_active) return;
+
+    // ---- epilogue: acc[m][j][e] <-> row m*16 + r16, column (tile0+j)*16 + q*4 + e
+    if constexpr (EPI == EPI_PARTIAL) {
+        float* base = a.partial + (long)blockIdx.y * a.slab_stride;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + r16;
+            if (row >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (tile0 + j) * 16 + q * 4;
+                if (tile0 + j < a.n_tiles && col < a.ldp)
+                    *reinterpret_cast<f32x4*>(base + (long)row * a.ldp + col) = acc[m][j];
+            }
+        }
+    } else if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + r16;
+            if (row >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (tile0 + j) * 16 + q * 4;
+                if (tile0 + j >= a.n_tiles || col >= a.N) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[m][j][e];
+                    if (a.bias) v += bf2f(a.bias[col + e]);
+                    o[e] = f2bf(v);
+                }
+                *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
+            }
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        // NT == 2: tile0 = gate tile, tile0+1 = up tile of the same 16 output columns
+        static_assert(EPI != EPI_SWIGLU || NT == 2, "swiglu epilogue needs gate/up tile pairs");
+        const int col = (tile0 / 2) * 16 + q * 4;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + r16;
+            if (row >= a.M || col >= a.N) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = rbf(acc[m][0][e]);              // gate_proj output (bf16)
+                const float sg = rbf(g / (1.0f + __expf(-g)));  // silu output (bf16)
+                const float u = rbf(acc[m][NT - 1][e]);         // up_proj output (bf16)
+                o[e] = f2bf(sg * u);
+            }
+            *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
+        }
+    } else {  // EPI_F32_RBF: fp32 logits that passed through a bf16 Linear output
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + r16;
+            if (row >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = (tile0 + j) * 16 + q * 4;
+                if (tile0 + j >= a.n_tiles) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < a.N) a.outf[(long)row * a.ldof + col + e] = rbf(acc[m][j][e]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Repack W[N][K] (row-major, ld = ldw) into fragment order.  dst tile index = nt*tile_stride +
+// tile_off lets the caller interleave several matrices (gate/up pairs, q|k|v concatenation).
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_w_kernel(const bf16* __restrict__ W, int N, int K, int ldw, bf16x8* __restrict__ Wp,
+                              int KS, int n_tiles_src, int tile_stride, int tile_off) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_tiles_src * KS * 64;
+    if (gid >= total) return;
+    const int lane = (int)(gid & 63);
+    const long rest = gid >> 6;
+    const int ks = (int)(rest % KS), nt = (int)(rest / KS);
+    const int n = nt * 16 + (lane & 15), k0 = ks * 32 + 8 * (lane >> 4);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (n < N && k0 + j < K) ? W[(long)n * ldw + k0 + j] : (bf16)0.0f;
+    Wp[((long)(nt * tile_stride + tile_off) * KS + ks) * 64 + lane] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side dispatch
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int KC, int EPI>
+static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
+    using C = WsCfg<MT, NT, KC>;
+    static bool attr_set = false;
+    auto kern = gemm_ws_kernel<MT, NT, KC, EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(ceil_div(a.n_tiles, 4 * NT), a.S);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, a);
+    return hipGetLastError();
+}
+
+template <int NT, int EPI>
+static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
+    // KC (k-steps of 32 per pipeline chunk) shrinks as the accumulator tile grows so that two
+    // weight register sets + accumulators stay under 256 VGPRs (2 waves/SIMD, no spills).
+    const int mt = ceil_div(a.M, 16);
+    if constexpr (NT == 1) {
+        if (mt <= 1) return launch_ws<1, 1, 8, EPI>(a, st);
+        if (mt <= 2) return launch_ws<2, 1, 8, EPI>(a, st);
+        if (mt <= 3) return launch_ws<3, 1, 8, EPI>(a, st);
+        if (mt <= 4) return launch_ws<4, 1, 8, EPI>(a, st);
+        if (mt <= 6) return launch_ws<6, 1, 4, EPI>(a, st);
+        if (mt <= 8) return launch_ws<8, 1, 4, EPI>(a, st);
+        if (mt <= 12) return launch_ws<12, 1, 2, EPI>(a, st);
+        if (mt <= 16) return launch_ws<16, 1, 2, EPI>(a, st);
+    } else {
+        if (mt <= 1) return launch_ws<1, 2, 8, EPI>(a, st);
+        if (mt <= 2) return launch_ws<2, 2, 4, EPI>(a, st);
+        if (mt <= 3) return launch_ws<3, 2, 4, EPI>(a, st);
+        if (mt <= 4) return launch_ws<4, 2, 4, EPI>(a, st);
+        if (mt <= 6) return launch_ws<6, 2, 2, EPI>(a, st);
+        if (mt <= 8) return launch_ws<8, 2, 2, EPI>(a, st);
+    }
+    return hipErrorInvalidValue;               // caller falls back to the tiled GEMM
+}
+
+// Largest M each epilogue supports here (the host routes bigger M to gemm_tile).
+extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 128 : 256; }
+
+extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, hipStream_t st) {
+    switch (epi) {
+        case EPI_PARTIAL: return dispatch_mt<1, EPI_PARTIAL>(*a, st);
+        case EPI_BF16: return dispatch_mt<1, EPI_BF16>(*a, st);
+        case EPI_SWIGLU: return dispatch_mt<2, EPI_SWIGLU>(*a, st);
+        case EPI_F32_RBF: return dispatch_mt<1, EPI_F32_RBF>(*a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, int tile_stride,
+                                 int tile_off, hipStream_t st) {
+    const int nts = ceil_div(N, 16);
+    const long total = (long)nts * KS * 64;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, N, K, ldw, Wp, KS, nts,
+                       tile_stride, tile_off);
+    return hipGetLastError();
+}

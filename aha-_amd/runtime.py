@@ -1,0 +1,245 @@
+"""Python host over the C ABI: device memory and streams come from PyTorch-ROCm (plumbing), every
+FLOP of the hot path runs in libaha_amd.so.  Nothing here imports ``oracle``."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import lib as _l
+from .config import LiveConfig
+
+_POOL_MODE = {"bilinear": 0, "average": 1, "max": 2}
+_POLICY = {None: _l.CACHE_NONE, "none": _l.CACHE_NONE, "default_sink": _l.CACHE_SINK,
+           "sliding_window": _l.CACHE_SLIDING, "static": _l.CACHE_STATIC}
+
+
+class AhaError(RuntimeError):
+    pass
+
+
+def _cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rope_table(n_pos: int, head_dim: int, theta: float):
+    """cos/sin exactly as Qwen2RotaryEmbedding.forward produces them (fp32 math, cast to bf16;
+    transformers modeling_qwen2.py:87-102): emb = cat(freqs, freqs)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    freqs = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(torch.bfloat16), emb.sin().to(torch.bfloat16)
+
+
+def rerotation_table(cos: torch.Tensor, sin: torch.Tensor, window: int, n_sink: int, T: int):
+    """SinkCache._get_rerotation_cos_sin (test/sink_cache.py:35-55) on rows [0, window) of the
+    bf16 RoPE table: rotate a kept key back by T positions."""
+    c = cos[:window].to(torch.float32)
+    s = sin[:window].to(torch.float32)
+    oc, sc = c[n_sink + T:], c[n_sink:-T]
+    os_, ss = s[n_sink + T:], s[n_sink:-T]
+    rc = oc * sc + os_ * ss
+    rs = -os_ * sc + oc * ss
+    return rc.to(torch.bfloat16).contiguous(), rs.to(torch.bfloat16).contiguous()
+
+
+class Stream:
+    """One video stream's KV state = the reference's Cache object (test/*_cache.py)."""
+
+    def __init__(self, rt: "Runtime", alt_cache: Optional[str], window_length: int, num_sink_tokens: int,
+                 capacity: int, attn_semantics: str = "trailing"):
+        self.rt = rt
+        self.policy = _POLICY[alt_cache]
+        self.window_length, self.num_sink_tokens = window_length, num_sink_tokens
+        h = C.c_void_p()
+        rt._chk(rt.lib.aha_stream_open(rt.ctx, self.policy, window_length, num_sink_tokens, capacity, C.byref(h)))
+        self.handle = h
+        if attn_semantics != "trailing":
+            rt._chk(rt.lib.aha_stream_set_attn_semantics(h, _l.ATTN_HF449_SDPA))
+
+    def reset(self):
+        self.rt._chk(self.rt.lib.aha_stream_reset(self.handle))
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.rt.lib.aha_stream_seq_length(self.handle)
+
+    @property
+    def seen_tokens(self) -> int:
+        return self.rt.lib.aha_stream_seen_tokens(self.handle)
+
+    def export_kv(self, layer: int, want_v: bool = False) -> torch.Tensor:
+        n = self.get_seq_length()
+        d = self.rt.desc
+        out = torch.empty((d.kv_heads, n, d.head_dim), dtype=torch.bfloat16, device=self.rt.device)
+        self.rt._chk(self.rt.lib.aha_stream_export_kv(self.rt.ctx, self.handle, layer, int(want_v), out.data_ptr(), _cur_stream()))
+        return out
+
+    def close(self):
+        if self.handle is not None and self.rt.ctx is not None:
+            self.rt.lib.aha_stream_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Runtime:
+    """aha_ctx owner: weights, tables, vision encode, LM step."""
+
+    def __init__(self, cfg: LiveConfig, weights: Dict[str, torch.Tensor], *, device: str = "cuda:0",
+                 max_step_tokens: int = 512, max_vit_frames: int = 32, max_positions: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise AhaError("aha_amd needs a GPU: the product path has no CPU fallback")
+        self.lib = _l.get()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        v, lm = cfg.vision, cfg.lm
+        self.desc = _l.ModelDesc(
+            image_size=v.image_size, patch_size=v.patch_size, v_hidden=v.hidden_size, v_layers=v.num_hidden_layers,
+            v_heads=v.num_attention_heads, v_inter=v.intermediate_size, v_ln_eps=v.layer_norm_eps,
+            hidden=lm.hidden_size, layers=lm.num_hidden_layers, heads=lm.num_attention_heads,
+            kv_heads=lm.num_key_value_heads, head_dim=lm.head_dim, inter=lm.intermediate_size, vocab=lm.vocab_size,
+            rope_theta=lm.rope_theta, rms_eps=lm.rms_norm_eps,
+            max_positions=max_positions or lm.max_position_embeddings, pool_stride=cfg.video_pooling_stride,
+            pool_mode=_POOL_MODE[cfg.mm_spatial_pool_mode], max_step_tokens=max_step_tokens, max_vit_frames=max_vit_frames)
+        ctx = C.c_void_p()
+        rc = self.lib.aha_ctx_create(C.byref(self.desc), self.device.index or 0, C.byref(ctx))
+        self.ctx = ctx
+        self._chk(rc)
+        self._load(weights)
+        cos, sin = rope_table(self.desc.max_positions, lm.head_dim, lm.rope_theta)
+        self._rope_cpu = (cos, sin)
+        cd, sd = cos.to(self.device), sin.to(self.device)
+        self._chk(self.lib.aha_ctx_set_rope_table(self.ctx, cd.data_ptr(), sd.data_ptr(), cos.shape[0], _cur_stream()))
+        self.frame_num_tokens = cfg.frame_num_tokens
+        self.hidden_size = lm.hidden_size
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            msg = self.lib.aha_last_error(self.ctx)
+            raise AhaError(f"aha_amd error {rc}: {msg.decode() if msg else ''}")
+
+    def _load(self, weights: Dict[str, torch.Tensor]):
+        keep, views = [], []
+        for name, t in weights.items():
+            t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            keep.append(t)
+            tv = _l.TensorView()
+            tv.name = name.encode()
+            tv.data = t.data_ptr()
+            tv.ndim = t.dim()
+            for i, s in enumerate(t.shape[:4]):
+                tv.shape[i] = s
+            if t.dim() == 4:                         # conv weight [Dv,3,P,P] is used as [Dv, 3*P*P]
+                tv.shape[0], tv.shape[1], tv.ndim = t.shape[0], t.shape[1] * t.shape[2] * t.shape[3], 2
+            views.append(tv)
+        arr = (_l.TensorView * len(views))(*views)
+        self._chk(self.lib.aha_ctx_load_weights(self.ctx, arr, len(views), _cur_stream()))
+        del keep
+
+    def set_tuning(self, key: str, value: int):
+        self._chk(self.lib.aha_ctx_set_tuning(self.ctx, key.encode(), int(value)))
+
+    def close(self):
+        if self.ctx is not None:
+            self.lib.aha_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    # -- streams ---------------------------------------------------------------------------------
+    def open_stream(self, alt_cache: Optional[str] = "default_sink", window_length: int = 2048, num_sink_tokens: int = 32,
+                    capacity: Optional[int] = None, attn_semantics: str = "trailing") -> Stream:
+        return Stream(self, alt_cache, window_length, num_sink_tokens, capacity or self.desc.max_positions, attn_semantics)
+
+    def _ensure_rerotation(self, s: Stream, T: int):
+        if s.policy != _l.CACHE_SINK:
+            return
+        W, k = s.window_length, s.num_sink_tokens
+        if W - k - T <= 0 or self.lib.aha_ctx_has_rerotation_table(self.ctx, W, k, T):
+            return
+        rc, rs = rerotation_table(self._rope_cpu[0], self._rope_cpu[1], W, k, T)
+        rc, rs = rc.to(self.device), rs.to(self.device)
+        self._chk(self.lib.aha_ctx_set_rerotation_table(self.ctx, W, k, T, rc.data_ptr(), rs.data_ptr(), _cur_stream()))
+
+    # -- the hot path ------------------------------------------------------------------------------
+    def visual_embed(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [N,3,S,S] on device -> bf16 [N*Tf, H] (LiveMixin.visual_embed, modeling_live.py:31-37,
+        with image_processor.preprocess fused in)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4
+        frames_u8 = frames_u8.contiguous()
+        n = frames_u8.shape[0]
+        out = torch.empty((n * self.frame_num_tokens, self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        step = self.desc.max_vit_frames
+        for i in range(0, n, step):
+            m = min(step, n - i)
+            self._chk(self.lib.aha_vit_encode(self.ctx, frames_u8[i:i + m].data_ptr(), m,
+                                              out[i * self.frame_num_tokens:].data_ptr(), _cur_stream()))
+        return out
+
+    def tower_output(self, n_frames: int) -> torch.Tensor:
+        """bf16 [n*Np, Dv] tower output of the last visual_embed call (test tap; copies)."""
+        rows, dv = n_frames * self.cfg.vision.num_patches, self.cfg.vision.hidden_size
+        out = torch.empty((rows, dv), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_vit_last_tower_output(self.ctx, n_frames, out.data_ptr(), _cur_stream()))
+        return out
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        ids = ids.to(device=self.device, dtype=torch.long).contiguous().view(-1)
+        out = torch.empty((ids.numel(), self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        if ids.numel():
+            self._chk(self.lib.aha_embed_tokens(self.ctx, ids.data_ptr(), ids.numel(), out.data_ptr(), _cur_stream()))
+        return out
+
+    def lm_step(self, streams: Sequence[Stream], embeds: torch.Tensor, *, want_raw: bool = False,
+                want_hidden: bool = False):
+        """embeds bf16 [B,T,H] -> scores fp32 [B,3] (+ raw head logits [B,4], last hidden [B,H])."""
+        assert embeds.is_cuda and embeds.dtype == torch.bfloat16 and embeds.dim() == 3
+        embeds = embeds.contiguous()
+        B, T, _ = embeds.shape
+        assert B == len(streams)
+        for s in streams:
+            self._ensure_rerotation(s, T)
+        scores = torch.empty((B, 3), dtype=torch.float32, device=self.device)
+        raw = torch.empty((B, 4), dtype=torch.float32, device=self.device) if want_raw else None
+        hid = torch.empty((B, self.hidden_size), dtype=torch.bfloat16, device=self.device) if want_hidden else None
+        arr = (C.c_void_p * B)(*[s.handle for s in streams])
+        self._chk(self.lib.aha_lm_step(self.ctx, arr, B, embeds.data_ptr(), T, scores.data_ptr(),
+                                       raw.data_ptr() if raw is not None else None,
+                                       hid.data_ptr() if hid is not None else None, _cur_stream()))
+        out = [scores]
+        if want_raw:
+            out.append(raw)
+        if want_hidden:
+            out.append(hid)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def heads_all(self, B: int, T: int) -> torch.Tensor:
+        raw = torch.empty((B * T, 4), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.aha_lm_heads_all(self.ctx, raw.data_ptr(), _cur_stream()))
+        return raw.view(B, T, 4)
+
+    def last_hidden_all(self, B: int, T: int) -> torch.Tensor:
+        out = torch.empty((B * T, self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_lm_last_hidden_all(self.ctx, out.data_ptr(), _cur_stream()))
+        return out.view(B, T, self.hidden_size)
+
+    def logits_last(self, B: int, want_logits: bool = True):
+        lg = torch.empty((B, self.cfg.lm.vocab_size), dtype=torch.float32, device=self.device) if want_logits else None
+        am = torch.empty((B,), dtype=torch.long, device=self.device)
+        self._chk(self.lib.aha_lm_logits_last(self.ctx, lg.data_ptr() if lg is not None else None, am.data_ptr(), _cur_stream()))
+        return lg, am
+
+    def last_step_work(self):
+        wb, kb, fl = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.aha_lm_last_step_work(self.ctx, C.byref(wb), C.byref(kb), C.byref(fl)))
+        return wb.value, kb.value, fl.value
+
+    def last_gemm_time(self, kind: int = 4):
+        ms, n, by = C.c_float(), C.c_int(), C.c_double()
+        self._chk(self.lib.aha_lm_last_gemm_time(self.ctx, kind, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value

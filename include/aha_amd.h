@@ -1,0 +1,138 @@
+/* aha_amd.h -- C ABI of the MI355X-native per-frame streaming-inference path.
+ *
+ * The reference (aiden200/Aha-) has no FFI or operator registry: its hot path sits behind
+ * Python method calls.  Each entry point below names the reference interface it
+ * serves; the Python host in aha-_amd/ (LiveInferForBenchmark / LiveInferForDemo / LiveLlava
+ * mirrors) is a thin ctypes caller of exactly these symbols.  INTEGRATION.md shows the binding
+ * a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code and never
+ * throws; aha_last_error() gives the message.  All tensor pointers are DEVICE pointers owned by
+ * the caller (bf16 unless stated); KV caches are owned by aha_stream.  Calls enqueue work on
+ * the given hipStream_t and do not synchronise.  One aha_ctx per process / GPU; not thread-safe.
+ */
+#ifndef AHA_AMD_H
+#define AHA_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aha_ctx aha_ctx;
+typedef struct aha_stream aha_stream;
+typedef void* aha_hip_stream;                 /* hipStream_t */
+
+/* Shapes.  Vision fields <- LLaVA-NeXT SigLIP tower config (call site
+ * models/live_llava/video_head_live_llava_qwen.py:107-115); LM fields <- Qwen2Config
+ * (:43-47,74); pooling <- video_pooling_stride / mm_spatial_pool_mode (:117-136). */
+typedef struct aha_model_desc {
+    int32_t image_size, patch_size, v_hidden, v_layers, v_heads, v_inter;
+    float v_ln_eps;
+    int32_t hidden, layers, heads, kv_heads, head_dim, inter, vocab;
+    float rope_theta, rms_eps;
+    int32_t max_positions;                    /* rows of the RoPE table */
+    int32_t pool_stride, pool_mode;           /* pool_mode: 0 bilinear, 1 average, 2 max */
+    int32_t max_step_tokens;                  /* largest B*T of one aha_lm_step */
+    int32_t max_vit_frames;                   /* largest n_frames of one aha_vit_encode */
+} aha_model_desc;
+
+/* One named checkpoint tensor (bf16, row-major, device memory).  Names are the checkpoint's:
+ * "model.layers.N.self_attn.q_proj.weight", "mm_projector.0.weight", "informative_head.weight",
+ * "vision.encoder.layers.N.mlp.fc1.weight", ... (aha-_amd/synth.py lists all of them). */
+typedef struct aha_tensor_view {
+    const char* name;
+    const void* data;
+    int64_t shape[4];
+    int32_t ndim;
+    int32_t reserved;
+} aha_tensor_view;
+
+/* alt_cache of LiveInferForBenchmark.__init__/_init_cache (test/inference.py:39,133-155) */
+enum { AHA_CACHE_NONE = 0,      /* past_key_values=None -> growing DynamicCache            */
+       AHA_CACHE_SINK = 1,      /* test/sink_cache.py SinkCache(window_length, num_sink)   */
+       AHA_CACHE_SLIDING = 2,   /* test/sliding_window_cache.py SlidingWindowCache(W)      */
+       AHA_CACHE_STATIC = 3 };  /* test/static_cache.py TrulyStaticCache(window_size)      */
+
+/* Attention-mask arithmetic (DESIGN.md "Mask semantics"): 0 = trailing-causal (parity target of
+ * SURVEY.md 8c), 1 = transformers-4.49 sdpa mask arithmetic. */
+enum { AHA_ATTN_TRAILING = 0, AHA_ATTN_HF449_SDPA = 1 };
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* replaces build_model_and_tokenizer()/build_live() model construction
+ * (models/__init__.py:8-11, models/modeling_live.py:96-181) for the inference path */
+int aha_ctx_create(const aha_model_desc* desc, int device, aha_ctx** out);
+/* replaces from_pretrained weight materialisation (models/modeling_live.py:137-144).  Tensors are
+ * COPIED and repacked into the kernels' private layouts; the caller may free them afterwards. */
+int aha_ctx_load_weights(aha_ctx* ctx, const aha_tensor_view* tensors, size_t n, aha_hip_stream st);
+/* RoPE cos/sin table, bf16 [n_pos][head_dim] (Qwen2RotaryEmbedding.forward output cast to bf16,
+ * transformers modeling_qwen2.py:87-102); copied. */
+int aha_ctx_set_rope_table(aha_ctx* ctx, const void* cos_bf16, const void* sin_bf16, int n_pos, aha_hip_stream st);
+/* SinkCache._get_rerotation_cos_sin table for new-token count T (test/sink_cache.py:35-55),
+ * bf16 [window - n_sink - T][head_dim]; copied, keyed by (window, n_sink, T). */
+int aha_ctx_set_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T, const void* cos_bf16,
+                                 const void* sin_bf16, aha_hip_stream st);
+int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
+/* tuning knobs: "split_qkv", "split_o", "split_down", "attn_split_len" (0 = heuristic) */
+int aha_ctx_set_tuning(aha_ctx* ctx, const char* key, int value);
+void aha_ctx_destroy(aha_ctx* ctx);
+const char* aha_last_error(aha_ctx* ctx);
+
+/* ---- vision: LiveMixin.visual_embed (models/modeling_live.py:31-37) on raw uint8 frames, i.e.
+ * image_processor.preprocess (test/inference.py:176) + vision_tower + mm_projector +
+ * post_projector_pooling (video_head_live_llava_qwen.py:107-136) ----------------------------- */
+/* frames_u8: [n,3,S,S] uint8 RGB; out_embeds: bf16 [n*Tf][hidden] */
+int aha_vit_encode(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* out_embeds, aha_hip_stream st);
+/* parity-test tap: copy the tower output of the last encode, bf16 [n_frames*Np][v_hidden] */
+int aha_vit_last_tower_output(aha_ctx* ctx, int n_frames, void* out, aha_hip_stream st);
+
+/* model.get_input_embeddings()(ids) (test/inference.py:212) */
+int aha_embed_tokens(aha_ctx* ctx, const int64_t* ids_dev, int n, void* out_embeds, aha_hip_stream st);
+
+/* ---- per-stream KV state: the Cache object of test/{sink,sliding_window,static}_cache.py -------- */
+/* capacity: slots for AHA_CACHE_NONE (others use window) */
+int aha_stream_open(aha_ctx* ctx, int policy, int window, int n_sink, int capacity, aha_stream** out);
+int aha_stream_reset(aha_stream* s);                       /* LiveInferForBenchmark.reset -> _init_cache */
+int aha_stream_seq_length(const aha_stream* s);            /* Cache.get_seq_length()      */
+int aha_stream_seen_tokens(const aha_stream* s);           /* Cache._seen_tokens          */
+int aha_stream_set_attn_semantics(aha_stream* s, int semantics);
+/* test tap: copy layer `layer`'s K or V as the attention sees it (logical order) into
+ * out bf16 [kv_heads][seq_len][head_dim] */
+int aha_stream_export_kv(aha_ctx* ctx, const aha_stream* s, int layer, int want_v, void* out, aha_hip_stream st);
+void aha_stream_destroy(aha_stream* s);
+
+/* ---- LM step: VideoHeadLiveLlavaQwenForCausalLM.forward inference branch
+ * (video_head_live_llava_qwen.py:156-188) on inputs_embeds [B,T,hidden] for B independent streams,
+ * including every layer's Cache.update, reduced to what _encode_frame reads
+ * (test/inference.py:217-227):
+ *   out_scores    fp32 [B][3] = softmax(informative_logits[b,-1])[1], relevance_logits[b,-1]
+ *                               (post-sigmoid), exp(uncertainty[b,-1])
+ *   out_raw_heads fp32 [B][4] (optional) = informative logits (2), relevance logit, log-variance
+ *   out_last_hidden bf16 [B][hidden] (optional) = final-norm hidden state of the last token */
+int aha_lm_step(aha_ctx* ctx, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
+                float* out_raw_heads, void* out_last_hidden, aha_hip_stream st);
+/* all-token head outputs of the last step: fp32 [B*T][4] (LiveLlava forward()'s informative_logits /
+ * relevance_logits(pre-sigmoid) / uncertainty for every position) */
+int aha_lm_heads_all(aha_ctx* ctx, float* out_raw_heads, aha_hip_stream st);
+/* copy the final-norm hidden states of the last step, bf16 [B*T][hidden] (outputs[0] of Qwen2Model) */
+int aha_lm_last_hidden_all(aha_ctx* ctx, void* out, aha_hip_stream st);
+/* lm_head on the last token of each stream of the last step (outputs.logits[:, -1]; used by
+ * _encode_query :261 and fast_greedy_generate, models/modeling_live.py:64-90):
+ * logits fp32 [B][vocab] (optional), argmax int64 [B] (optional) */
+int aha_lm_logits_last(aha_ctx* ctx, float* logits, int64_t* argmax, aha_hip_stream st);
+
+/* ---- introspection ------------------------------------------------------------------------- */
+/* algorithmic bytes / flops of the last aha_lm_step (SURVEY.md 8d accounting) */
+int aha_lm_last_step_work(aha_ctx* ctx, double* weight_bytes, double* kv_bytes, double* flops);
+/* time of the weight-streaming GEMM launches of the last step, measured with HIP events on the
+ * launch stream when enabled with aha_ctx_set_tuning("time_gemm", 1).  kind: 0 qkv, 1 o_proj,
+ * 2 gate/up(+SwiGLU), 3 down_proj, 4 all.  Returns summed ms, launch count and the packed weight
+ * bytes those launches streamed.  Synchronises on the recorded events. */
+int aha_lm_last_gemm_time(aha_ctx* ctx, int kind, float* ms, int* launches, double* gemm_weight_bytes);
+const char* aha_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AHA_AMD_H */

@@ -1,0 +1,186 @@
+"""GPU parity: the HIP path (through the C ABI, via aha_amd.runtime) against the oracle on the
+same seeded weights and inputs.  Floating-point path: tolerances are written next to each check.
+
+Tolerance rationale: both sides compute in bf16 with fp32 accumulation but sum in different orders,
+so hidden states agree to a few bf16 ulps; the scores (sigmoid/softmax/exp of bf16-rounded head
+logits) are held to the 1e-3 of BASELINE.json's north star on the small configs, and on 7B-shaped
+layers to the measured bf16 noise band of the oracle itself (|oracle_bf16 - oracle_fp32|).
+"""
+import numpy as np
+import pytest
+import torch
+
+import aha_amd  # noqa: F401
+from aha_amd.config import preset
+from aha_amd.synth import make_frames, make_weights
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-3          # north star: per-frame scores within 1e-3 (bf16)
+
+
+def _rt(cfg, w, **kw):
+    from aha_amd.runtime import Runtime
+    return Runtime(cfg, w, **kw)
+
+
+def _oracle_policy(name, W, S):
+    from oracle.cache_policies import make_policy
+    return make_policy(name, W, S)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=128, max_vit_frames=4, max_positions=4096)
+    yield cfg, w, rt
+    rt.close()
+
+
+@pytest.fixture(scope="module")
+def tiny128():
+    cfg = preset("tiny128")
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=256, max_vit_frames=4, max_positions=4096)
+    yield cfg, w, rt
+    rt.close()
+
+
+def test_vision_tower_and_embed_parity(tiny):
+    from oracle.vision_tower import OracleVision, preprocess
+    cfg, w, rt = tiny
+    fr = make_frames(3, cfg.vision.image_size, seed=0)
+    ov = OracleVision(cfg, w, torch.bfloat16)
+    want_tower = ov.tower(preprocess(fr, torch.bfloat16)).float()
+    want_embed = ov.visual_embed(fr).float()
+    got_embed = rt.visual_embed(fr.cuda()).float().cpu()
+    got_tower = rt.tower_output(3).float().cpu().view_as(want_tower)
+    # values are O(1); bf16 ulp at 1.0 is 2^-8 = 0.0039; allow 4 ulps of the running magnitude
+    assert (got_tower - want_tower).abs().max().item() <= 0.03 * max(1.0, want_tower.abs().max().item())
+    assert (got_embed - want_embed).abs().max().item() <= 0.03 * max(1.0, want_embed.abs().max().item())
+    assert got_embed.shape == (3 * cfg.frame_num_tokens, cfg.lm.hidden_size)
+
+
+@pytest.mark.parametrize("which", ["tiny", "tiny128"])
+@pytest.mark.parametrize("policy", ["default_sink", "sliding_window", "static", None])
+def test_lm_step_parity(which, policy, request):
+    from oracle.qwen2_live import OracleLM, frame_scores
+    cfg, w, rt = request.getfixturevalue(which)
+    W, S = 40, 6
+    o = OracleLM(cfg.lm, w, torch.bfloat16)
+    oc = _oracle_policy(policy, W, S)
+    st = rt.open_stream(policy, W, S, capacity=512)
+    g = torch.Generator().manual_seed(21)
+    worst_s, worst_h = 0.0, 0.0
+    for step, T in enumerate([13, 5, 5, 5, 9, 5, 5, 1, 5, 5, 5, 5]):
+        x = (torch.randn(1, T, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16()
+        want = o.step(x, oc)
+        got_s, got_raw, got_h = rt.lm_step([st], x.cuda(), want_raw=True, want_hidden=True)
+        assert st.get_seq_length() == oc.get_seq_length(), (step, st.get_seq_length(), oc.get_seq_length())
+        ws = frame_scores(want)
+        worst_s = max(worst_s, (got_s.cpu() - ws).abs().max().item())
+        worst_h = max(worst_h, (got_h.float().cpu() - want["hidden"][:, -1].float()).abs().max().item())
+    assert worst_h <= 0.12, worst_h            # final-norm hidden, |h| up to ~4: a few bf16 ulps (2^-6 at 2..4)
+    assert worst_s <= SCORE_TOL * 3, worst_s   # tiny random nets are the noisiest case; 7B-shaped test uses SCORE_TOL band
+    st.close()
+
+
+def test_sink_rerotation_and_ring_are_bit_exact(tiny128):
+    """Kept keys after an eviction step == reference re-rotation of the kept keys before it, bit for
+    bit; kept values unchanged (test/sink_cache.py:134-162), through the ring layout."""
+    from aha_amd.runtime import rerotation_table, rope_table
+    cfg, w, rt = tiny128
+    W, S, T = 48, 4, 7
+    st = rt.open_stream("default_sink", W, S)
+    g = torch.Generator().manual_seed(5)
+    cos, sin = rope_table(4096, cfg.lm.head_dim, cfg.lm.rope_theta)
+    for step in range(10):
+        before_k = [st.export_kv(l).cpu() for l in range(cfg.lm.num_hidden_layers)]
+        before_v = [st.export_kv(l, True).cpu() for l in range(cfg.lm.num_hidden_layers)]
+        L = st.get_seq_length()
+        x = (torch.randn(1, T, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16()
+        rt.lm_step([st], x.cuda())
+        if L + T < W:
+            continue
+        keep = W - S - T
+        rc, rs = rerotation_table(cos, sin, W, S, T)
+        for l in range(cfg.lm.num_hidden_layers):
+            after_k, after_v = st.export_kv(l).cpu(), st.export_kv(l, True).cpu()
+            kk = before_k[l][:, -keep:]
+            h = kk.shape[-1] // 2
+            rot = torch.cat((-kk[..., h:], kk[..., :h]), dim=-1)
+            want = (kk * rc[None]) + (rot * rs[None])
+            assert torch.equal(after_k[:, :S], before_k[l][:, :S])
+            assert torch.equal(after_k[:, S:S + keep], want), (step, l)
+            assert torch.equal(after_v[:, S:S + keep], before_v[l][:, -keep:])
+            assert torch.equal(after_v[:, :S], before_v[l][:, :S])
+    assert st.get_seq_length() == W and st.seen_tokens == 10 * T
+    st.close()
+
+
+def test_batched_streams_match_single_stream(tiny128):
+    """B independent streams in one step == each stream stepped alone (streams never mix)."""
+    cfg, w, rt = tiny128
+    pol = [("default_sink", 40, 4), ("sliding_window", 32, 0), (None, 0, 0)]
+    solo = [rt.open_stream(p, W or 2048, S, capacity=256) for p, W, S in pol]
+    both = [rt.open_stream(p, W or 2048, S, capacity=256) for p, W, S in pol]
+    g = torch.Generator().manual_seed(8)
+    for step in range(8):
+        x = (torch.randn(3, 9, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16().cuda()
+        sb = rt.lm_step(both, x).cpu()
+        for i in range(3):
+            ss = rt.lm_step([solo[i]], x[i:i + 1]).cpu()
+            assert (ss[0] - sb[i]).abs().max().item() <= 2e-3, (step, i)
+            assert solo[i].get_seq_length() == both[i].get_seq_length()
+    for s in solo + both:
+        s.close()
+
+
+def test_logits_last_and_embed_tokens(tiny):
+    from oracle.qwen2_live import OracleLM
+    from oracle.cache_policies import GrowingPolicy
+    cfg, w, rt = tiny
+    o = OracleLM(cfg.lm, w, torch.bfloat16)
+    ids = torch.tensor([[3, 17, 200, 5, 511, 0, 42]])
+    emb = rt.embed_tokens(ids.cuda())
+    assert torch.equal(emb.cpu(), o.embed_tokens(ids)[0])
+    st = rt.open_stream(None, capacity=64)
+    rt.lm_step([st], emb.view(1, -1, cfg.lm.hidden_size))
+    lg, am = rt.logits_last(1)
+    want = o.step(o.embed_tokens(ids), GrowingPolicy(), want_logits=True)["logits"][:, -1]
+    assert (lg.cpu() - want).abs().max().item() <= 0.06
+    assert lg.cpu().argmax(-1).item() == am.item()
+    st.close()
+
+
+def test_heads_all_and_hidden_all(tiny):
+    from oracle.qwen2_live import OracleLM
+    from oracle.cache_policies import GrowingPolicy
+    cfg, w, rt = tiny
+    o = OracleLM(cfg.lm, w, torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(1, 6, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16()
+    st = rt.open_stream(None, capacity=64)
+    rt.lm_step([st], x.cuda())
+    raw = rt.heads_all(1, 6).cpu()
+    hid = rt.last_hidden_all(1, 6).float().cpu()
+    want = o.step(x, GrowingPolicy())
+    assert (hid - want["hidden"].float()).abs().max().item() <= 0.12
+    assert (raw[..., :2] - want["informative_logits"]).abs().max().item() <= 0.02
+    assert (torch.sigmoid(raw[..., 2:3]) - want["relevance_logits"]).abs().max().item() <= 5e-3
+    assert (raw[..., 3:4] - want["uncertainty"]).abs().max().item() <= 0.02
+    st.close()
+
+
+def test_errors_are_reported_not_crashed(tiny):
+    from aha_amd.runtime import AhaError
+    cfg, w, rt = tiny
+    st = rt.open_stream("sliding_window", 16, 0)
+    x = torch.zeros(1, 20, cfg.lm.hidden_size, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(AhaError):
+        rt.lm_step([st], x)                      # T > window
+    assert st.get_seq_length() == 0              # rolled back
+    with pytest.raises(AhaError):
+        rt.lm_step([st, st], torch.zeros(2, 4, cfg.lm.hidden_size, dtype=torch.bfloat16, device="cuda"))
+    st.close()
