@@ -600,7 +600,7 @@ static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_
 static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
                    bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
     const int mmax = aha_gemm_ws_max_m(epi);
-    const bool timed = c->time_gemm && kind >= 0;
+    const bool timed = kind >= 0 && ((c->time_gemm >> kind) & 1);      // time_gemm: bit k = GEMM kind k
     if (timed) {
         if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
             hipEvent_t a, b;

@@ -72,6 +72,8 @@ class Stream:
         n = self.get_seq_length()
         d = self.rt.desc
         out = torch.empty((d.kv_heads, n, d.head_dim), dtype=torch.bfloat16, device=self.rt.device)
+        if n == 0:
+            return out
         self.rt._chk(self.rt.lib.aha_stream_export_kv(self.rt.ctx, self.handle, layer, int(want_v), out.data_ptr(), _cur_stream()))
         return out
 

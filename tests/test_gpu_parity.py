@@ -24,6 +24,12 @@ def _rt(cfg, w, **kw):
     return Runtime(cfg, w, **kw)
 
 
+def _rel_unc(s):
+    """scores [B,3]: informative and relevance are probabilities (absolute error); the third is
+    exp(log-variance), unbounded, so it is compared in log space (= error of the bf16 logit)."""
+    return torch.stack([s[:, 0], s[:, 1], torch.log(s[:, 2])], dim=-1)
+
+
 def _oracle_policy(name, W, S):
     from oracle.cache_policies import make_policy
     return make_policy(name, W, S)
@@ -69,20 +75,28 @@ def test_lm_step_parity(which, policy, request):
     cfg, w, rt = request.getfixturevalue(which)
     W, S = 40, 6
     o = OracleLM(cfg.lm, w, torch.bfloat16)
-    oc = _oracle_policy(policy, W, S)
+    o32 = OracleLM(cfg.lm, w, torch.float32)
+    oc, oc32 = _oracle_policy(policy, W, S), _oracle_policy(policy, W, S)
     st = rt.open_stream(policy, W, S, capacity=512)
     g = torch.Generator().manual_seed(21)
-    worst_s, worst_h = 0.0, 0.0
+    d_bf, d_32, band, worst_h = 0.0, 0.0, 0.0, 0.0
     for step, T in enumerate([13, 5, 5, 5, 9, 5, 5, 1, 5, 5, 5, 5]):
         x = (torch.randn(1, T, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16()
         want = o.step(x, oc)
+        s32 = _rel_unc(frame_scores(o32.step(x.float(), oc32)))
         got_s, got_raw, got_h = rt.lm_step([st], x.cuda(), want_raw=True, want_hidden=True)
         assert st.get_seq_length() == oc.get_seq_length(), (step, st.get_seq_length(), oc.get_seq_length())
-        ws = frame_scores(want)
-        worst_s = max(worst_s, (got_s.cpu() - ws).abs().max().item())
+        ws, gs = _rel_unc(frame_scores(want)), _rel_unc(got_s.cpu())
+        d_bf = max(d_bf, (gs - ws).abs().max().item())
+        d_32 = max(d_32, (gs - s32).abs().max().item())
+        band = max(band, (ws - s32).abs().max().item())
         worst_h = max(worst_h, (got_h.float().cpu() - want["hidden"][:, -1].float()).abs().max().item())
     assert worst_h <= 0.12, worst_h            # final-norm hidden, |h| up to ~4: a few bf16 ulps (2^-6 at 2..4)
-    assert worst_s <= SCORE_TOL * 3, worst_s   # tiny random nets are the noisiest case; 7B-shaped test uses SCORE_TOL band
+    # band = the reference arithmetic's own bf16 error against fp32 on this sequence (2e-3..8e-3 here:
+    # head logits are bf16 Linear outputs, one ulp moves a score by >= 1e-3).  The HIP path must be as
+    # close to the fp32 truth as that, and within two bands of the bf16 oracle.
+    assert d_32 <= max(SCORE_TOL, 2.0 * band), (d_32, band)
+    assert d_bf <= max(SCORE_TOL, 3.0 * band), (d_bf, band)
     st.close()
 
 
