@@ -61,6 +61,7 @@ struct aha_ctx {
          *v_p1 = nullptr, *v_p2 = nullptr;
     // tuning
     int split[GK_COUNT] = {0, 0, 0, 0};
+    int wpb[GK_COUNT] = {4, 4, 4, 4};
     int attn_split_len = 0;
     int time_gemm = 0;
     // accounting of the last step
@@ -178,6 +179,10 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "split_o") c->split[GK_O] = value;
     else if (k == "split_gateup") c->split[GK_GATEUP] = value;   // ignored by the fused SwiGLU epilogue (always 1)
     else if (k == "split_down") c->split[GK_DOWN] = value;
+    else if (k == "wpb_qkv") c->wpb[GK_QKV] = value;
+    else if (k == "wpb_o") c->wpb[GK_O] = value;
+    else if (k == "wpb_gateup") c->wpb[GK_GATEUP] = value;
+    else if (k == "wpb_down") c->wpb[GK_DOWN] = value;
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
@@ -587,7 +592,7 @@ static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_
     const int nc = ceil_div(w.KS, kc);
     int S = c->split[kind];
     if (S <= 0) {
-        const int nblk = ceil_div(w.n_tiles, 4 * nt_per_wave);
+        const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);
         S = 512 / (nblk > 0 ? nblk : 1);
         if (S > 8) S = 8;
     }
@@ -619,7 +624,7 @@ static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const Pa
         a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
         a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;
         a.bias = nullptr; a.N = w.N;
-        HIPCHK(c, aha_gemm_ws(&a, epi, st));
+        HIPCHK(c, aha_gemm_ws(&a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
     }
     if (timed) {
         HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].second, st));

@@ -14,8 +14,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;      // one 16x16 MFMA 
 
 static __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 static __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
-// round-trip through bf16: the rounding point a torch bf16 op output has
-static __device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }
+// Round to bf16 and back: the rounding point a torch bf16 op output has.  Done with explicit
+// integer round-to-nearest-even: hipcc (ROCm 7.2) may keep excess precision across a
+// (float)(__bf16)x round trip inside one expression and silently skip the rounding (observed in
+// the RoPE re-rotation kernel: results equal to UNROUNDED arithmetic).  Finite inputs only.
+static __device__ __forceinline__ float rbf(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
 
 static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     // D[16x16] += A[16x32] * B[32x16]; lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];

@@ -54,24 +54,47 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
 // lin_bf16 != null replaces the slab sum (tiled-GEMM fallback path).
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
-    __shared__ float red[4];
-    const int row = blockIdx.x, tid = threadIdx.x, nch = a.H >> 3;
-    float hv[4][8];
+// One 16-B chunk of the row per thread (blockDim = H/8 rounded up to waves, <= 1024): every slab
+// load of the thread is independent and issued back to back, so the kernel costs about two
+// memory latencies instead of S of them.
+static __device__ __forceinline__ float block_sum_any(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(512) void resid_norm_kernel(ResidNormArgs a) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, nch = a.H >> 3;
     float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256;
+    for (int c0 = 0; c0 < nch; c0 += blockDim.x) {          // one pass when H/8 <= blockDim
+        const int c = c0 + threadIdx.x;
+        float f8[8];
         if (c < nch) {
             float lin[8];
             if (a.partial) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) lin[e] = 0.f;
-                for (int s = 0; s < a.S; ++s) {
-                    const float* p = a.partial + s * a.slab_stride + (long)row * a.ldp + c * 8;
-                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+                const float* p = a.partial + (long)row * a.ldp + c * 8;
+                for (int s0 = 0; s0 < a.S; s0 += 8) {
+                    f32x4 p0[8], p1[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { lin[e] += p0[e]; lin[4 + e] += p1[e]; }
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < a.S) {
+                            p0[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride);
+                            p1[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride + 4);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < a.S) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lin[e] += p0[j][e]; lin[4 + e] += p1[j][e]; }
+                        }
                 }
             } else {
                 const bf16x8 lv = *reinterpret_cast<const bf16x8*>(a.lin_bf16 + (long)row * a.ldl + c * 8);
@@ -83,25 +106,35 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = rbf(bf2f(hh[e]) + rbf(lin[e]));
-                hv[i][e] = f;
+                f8[e] = f;
                 ho[e] = f2bf(f);
                 ss += f * f;
             }
             *reinterpret_cast<bf16x8*>(a.h + (long)row * a.ldh + c * 8) = ho;
         }
-    }
-    ss = block_sum_256(ss, red);
-    const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+        if (nch <= (int)blockDim.x) {                       // common case: keep the row in registers
+            ss = block_sum_any(ss, red);
+            const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+            if (c < nch) {
+                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
+                bf16x8 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + i * 256;
-        if (c < nch) {
-            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(hv[i][e] * rstd));
-            *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));
+                *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+            }
+            return;
         }
+    }
+    // H/8 > blockDim (H > 8192): second pass re-reads the updated residual row
+    ss = block_sum_any(ss, red);
+    const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(hh[e]) * rstd));
+        *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
     }
 }
 
@@ -112,7 +145,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
 // ---------------------------------------------------------------------------------------------
 
 template <int D>
-__global__ __launch_bounds__(256) void qkv_finish_kernel(QkvFinishArgs a, StepDesc sd) {
+__global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, StepDesc sd) {
     constexpr int HALF = D / 2, IPH = HALF / 4;           // items (4 rotation pairs) per head
     const int row = blockIdx.x, tid = threadIdx.x;
     const int b = row / sd.T, t = row % sd.T;
@@ -127,8 +160,16 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(QkvFinishArgs a, StepDe
     auto fetch4 = [&](int col, float (&o)[4]) {
         if (a.partial) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < a.S; ++s)
-                acc += *reinterpret_cast<const f32x4*>(a.partial + s * a.slab_stride + (long)row * a.ldp + col);
+            const float* p = a.partial + (long)row * a.ldp + col;
+            for (int s0 = 0; s0 < a.S; s0 += 8) {
+                f32x4 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j < a.S) t[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j < a.S) acc += t[j];
+            }
             const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + col);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rbf(acc[e] + bf2f(bv[e]));
@@ -139,7 +180,7 @@ __global__ __launch_bounds__(256) void qkv_finish_kernel(QkvFinishArgs a, StepDe
         }
     };
 
-    for (int it = tid; it < qk_items + v_items; it += 256) {
+    for (int it = tid; it < qk_items + v_items; it += blockDim.x) {
         if (it < qk_items) {
             const int head = it / IPH, d = (it % IPH) * 4;     // head < Hq: query head, else key head
             const int col = head * D + d;
@@ -419,13 +460,17 @@ hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo
 hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     if ((a->H & 7) || a->H > 8192) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(resid_norm_kernel, dim3(M), dim3(256), 0, st, *a);
+    int threads = round_up(a->H >> 3, 64);
+    if (threads > 512) threads = 512;
+    hipLaunchKernelGGL(resid_norm_kernel, dim3(M), dim3(threads), 0, st, *a);
     return hipGetLastError();
 }
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st) {
     const int M = sd->B * sd->T;
-    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M), dim3(256), 0, st, *a, *sd);
-    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M), dim3(256), 0, st, *a, *sd);
+    int threads = round_up((a->Hq + a->Hkv) * (a->D / 8) + a->Hkv * (a->D / 4), 64);   // one item per thread
+    if (threads > 1024) threads = 1024;
+    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M), dim3(threads), 0, st, *a, *sd);
+    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M), dim3(threads), 0, st, *a, *sd);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -20,25 +20,26 @@
 #include "aha_kernels.h"
 
 
-template <int MT, int NT, int KC>
+template <int MT, int NT, int KC, int WPB>
 struct WsCfg {
+    static constexpr int THREADS = WPB * 64;
     static constexpr int MPAD = MT * 16;
     static constexpr int STRIDE = KC * 32 + 8;                 // bf16 elements per LDS row
     static constexpr int BUF = MPAD * STRIDE;                  // elements per buffer
     static constexpr int LDS_BYTES = 2 * BUF * 2;
     static constexpr int XCH = MPAD * KC * 4;                  // 16-B chunks per X chunk tile
-    static constexpr int XLD = (XCH + 255) / 256;              // staging loads per thread
+    static constexpr int XLD = (XCH + THREADS - 1) / THREADS;   // staging loads per thread
 };
 
-template <int MT, int NT, int KC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmWsArgs a) {
-    using C = WsCfg<MT, NT, KC>;
+template <int MT, int NT, int KC, int EPI, int WPB>
+__global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
+    using C = WsCfg<MT, NT, KC, WPB>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* xs = reinterpret_cast<bf16*>(smem_raw);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r16 = lane & 15;
-    const int tile0 = (blockIdx.x * 4 + wave) * NT;            // first n-tile of this wave
+    const int tile0 = (blockIdx.x * WPB + wave) * NT;            // first n-tile of this wave
     const bool wave_active = tile0 < a.n_tiles;
     const int NC = (a.KS + KC - 1) / KC;                       // chunks over the whole K
     const int c0 = (int)(((long)blockIdx.y * NC) / a.S), c1 = (int)(((long)(blockIdx.y + 1) * NC) / a.S);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmWsArgs a) {
         const int kbase = c * KC * 32;
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * C::THREADS;
             int row = idx / (KC * 4), cc = idx % (KC * 4);
             if (row > a.M - 1) row = a.M - 1;                   // padded rows: finite duplicates, never stored
             const int k = kbase + cc * 8;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(GemmWsArgs a) {
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * C::THREADS;
             const int row = idx / (KC * 4), cc = idx % (KC * 4);
             if (idx < C::XCH)
                 *reinterpret_cast<bf16x8*>(xs + buf * C::BUF + row * C::STRIDE + cc * 8) = xr[i];
@@ -213,19 +214,29 @@ __global__ void pack_w_kernel(const bf16* __restrict__ W, int N, int K, int ldw,
 // ---------------------------------------------------------------------------------------------
 // Host-side dispatch
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int KC, int EPI>
-static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
-    using C = WsCfg<MT, NT, KC>;
+template <int MT, int NT, int KC, int EPI, int WPB>
+static hipError_t launch_ws_w(const GemmWsArgs& a, hipStream_t st) {
+    using C = WsCfg<MT, NT, KC, WPB>;
     static bool attr_set = false;
-    auto kern = gemm_ws_kernel<MT, NT, KC, EPI>;
+    auto kern = gemm_ws_kernel<MT, NT, KC, EPI, WPB>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    dim3 grid(ceil_div(a.n_tiles, 4 * NT), a.S);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, a);
+    dim3 grid(ceil_div(a.n_tiles, WPB * NT), a.S);
+    hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, st, a);
     return hipGetLastError();
+}
+
+static thread_local int g_wpb = 4;      // waves per workgroup for the next dispatch (2 or 4)
+
+template <int MT, int NT, int KC, int EPI>
+static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
+    if constexpr (MT <= 4) {            // the 2-wave variant exists for the single-stream shapes
+        if (g_wpb == 2) return launch_ws_w<MT, NT, KC, EPI, 2>(a, st);
+    }
+    return launch_ws_w<MT, NT, KC, EPI, 4>(a, st);
 }
 
 template <int NT, int EPI>
@@ -256,7 +267,8 @@ static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
 // Largest M each epilogue supports here (the host routes bigger M to gemm_tile).
 extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 128 : 256; }
 
-extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, hipStream_t st) {
+extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
+    g_wpb = (wpb == 2) ? 2 : 4;
     switch (epi) {
         case EPI_PARTIAL: return dispatch_mt<1, EPI_PARTIAL>(*a, st);
         case EPI_BF16: return dispatch_mt<1, EPI_BF16>(*a, st);
