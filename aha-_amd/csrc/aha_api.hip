@@ -61,7 +61,7 @@ struct aha_ctx {
          *v_p1 = nullptr, *v_p2 = nullptr;
     // tuning
     int split[GK_COUNT] = {0, 0, 0, 0};
-    int wpb[GK_COUNT] = {4, 4, 4, 4};
+    int wpb[GK_COUNT] = {4, 4, 8, 8};        // waves per workgroup per GEMM kind (measured: tools/tune_lm.py)
     int attn_split_len = 0;
     int time_gemm = 0;
     // accounting of the last step
@@ -217,7 +217,7 @@ static int copy_vec(aha_ctx* c, const TMap& m, const std::string& name, int64_t 
 static int alloc_packed(aha_ctx* c, PackedW* w, int n_tiles, int K) {
     w->n_tiles = n_tiles;
     w->K = K;
-    w->KS = K / 32;
+    w->KS = round_up(ceil_div(K, 32), 8);        // whole chunks for every KC in {1,2,4,8}; pack_w zero-fills k >= K
     return dalloc(c, &w->p, (size_t)n_tiles * w->KS * 64);
 }
 
@@ -588,8 +588,8 @@ extern "C" int aha_embed_tokens(aha_ctx* c, const int64_t* ids, int n, void* out
 // --------------------------------------------------------------------------------------------
 static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave) {
     const int mt = ceil_div(M < 256 ? M : 256, 16);
-    int kc = nt_per_wave == 1 ? (mt <= 4 ? 8 : mt <= 8 ? 4 : 2) : (mt <= 1 ? 8 : mt <= 4 ? 4 : 2);
-    const int nc = ceil_div(w.KS, kc);
+    int kc = nt_per_wave == 1 ? (mt <= 3 ? 8 : mt <= 4 ? 4 : mt <= 8 ? 2 : 1) : (mt <= 4 ? 4 : 2);   // mirrors dispatch_mt
+    const int nc = w.KS / kc;
     int S = c->split[kind];
     if (S <= 0) {
         const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);
@@ -619,7 +619,7 @@ static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const Pa
         GemmWsArgs a;
         memset(&a, 0, sizeof(a));
         a.X = X + (long)m0 * ldx; a.ldx = ldx; a.M = (M - m0 < mmax) ? M - m0 : mmax;
-        a.Wp = w.p; a.KS = w.KS; a.n_tiles = w.n_tiles; a.S = S;
+        a.Wp = w.p; a.KS = w.KS; a.Kx = w.K; a.n_tiles = w.n_tiles; a.S = S;
         a.partial = partial ? partial + (long)m0 * ldp : nullptr; a.ldp = ldp; a.slab_stride = (long)M * ldp;
         a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
         a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;

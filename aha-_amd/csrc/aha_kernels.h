@@ -6,7 +6,8 @@ enum { EPI_PARTIAL = 0, EPI_BF16 = 1, EPI_SWIGLU = 2, EPI_F32_RBF = 3 };
 
 struct GemmWsArgs {
     const bf16* X; int ldx; int M;
-    const bf16x8* Wp; int KS;        // k-steps of 32 (K = KS*32)
+    const bf16x8* Wp; int KS;        // k-steps of 32 in the packed weight (padded to a multiple of 8, zero-filled)
+    int Kx;                          // valid columns of X (= the weight's real K)
     int n_tiles;                     // 16-row tiles of the packed weight (N_pad/16)
     int S;                           // split-K factor (gridDim.y)
     float* partial; int ldp; long slab_stride;  // EPI_PARTIAL: slab s at partial + s*slab_stride, rows [M][ldp]

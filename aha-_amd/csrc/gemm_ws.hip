@@ -5,8 +5,8 @@
 //   * W is repacked ONCE at load into MFMA-fragment order  Wp[n_tile][k_step][lane][8 bf16]
 //     (element W[nt*16 + (lane&15)][ks*32 + 8*(lane>>4) + j]), so a wave's weight stream for its
 //     n-tile is a linear sequence of 1 KiB wave-loads (16 B/lane, perfectly coalesced, each byte
-//     read exactly once) that goes straight to VGPRs as the MFMA A operand - no LDS round trip
-//     for the operand that is streamed once (guide: "GEMV / M<=16 decode weights" row).
+//     read exactly once, nontemporal) that goes straight to VGPRs as the MFMA A operand - no LDS
+//     round trip for the operand that is streamed once (guide: "GEMV / M<=16 decode weights").
 //   * X (M x K, L2-resident, re-read by every workgroup) goes through LDS in full rows
 //     (coalesced 16-B loads, padded row stride => conflict-free ds_read_b128 B-fragments).
 //   * v_mfma_f32_16x16x32_bf16 with A = W fragment, B = X^T fragment: the accumulator holds
@@ -14,11 +14,18 @@
 //   * K is split across blockIdx.y (split-K) so every CU streams; partial sums go to fp32 slabs
 //     that the NEXT kernel's prologue reduces (qkv_finish / resid_norm) - no extra launch, no
 //     atomics, bitwise reproducible.
-//   * Software pipeline: weights for chunk c+1 are in flight in a second register set while
-//     chunk c computes; X for chunk c+1 is loaded before them (vmcnt is in-order) and written to
-//     the other LDS buffer after the compute.  One barrier per chunk.
+//   * Software pipeline, three rotating weight register sets: while chunk c computes, chunks c+1
+//     AND c+2 are in flight (a wave's throughput is in-flight bytes / HBM latency, and these
+//     kernels have only 4-9 waves per CU).  Per step, in this order because vmcnt is in-order:
+//     X(c+1) loads -> W(c+2) loads -> MFMAs of chunk c (wait: W(c), the oldest) -> LDS store of
+//     X(c+1) (wait: X(c+1); the younger W(c+2) stays in flight across the barrier) -> barrier.
+//   * What the ISA taught (ROCm 7.2 hipcc): (1) a guarded load becomes its own basic block and
+//     the waits degrade to vmcnt(0): every load here is unconditional, indices are clamped into
+//     valid memory instead; (2) a prefetch under an `if` makes the count of younger loads unknown
+//     at the join (vmcnt(0) again): the steady-state body is one straight-line block of 3 steps,
+//     the remainder is peeled at the FRONT as rotate-by-copy steps, the tail is fixed;
+//     (3) sched_barrier(0) pins the X-before-W issue order the counted waits rely on.
 #include "aha_kernels.h"
-
 
 template <int MT, int NT, int KC, int WPB>
 struct WsCfg {
@@ -28,7 +35,7 @@ struct WsCfg {
     static constexpr int BUF = MPAD * STRIDE;                  // elements per buffer
     static constexpr int LDS_BYTES = 2 * BUF * 2;
     static constexpr int XCH = MPAD * KC * 4;                  // 16-B chunks per X chunk tile
-    static constexpr int XLD = (XCH + THREADS - 1) / THREADS;   // staging loads per thread
+    static constexpr int XLD = (XCH + THREADS - 1) / THREADS;  // staging loads per thread
 };
 
 template <int MT, int NT, int KC, int EPI, int WPB>
@@ -39,9 +46,16 @@ __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r16 = lane & 15;
-    const int tile0 = (blockIdx.x * WPB + wave) * NT;            // first n-tile of this wave
+    const int tile0 = (blockIdx.x * WPB + wave) * NT;          // first n-tile of this wave
     const bool wave_active = tile0 < a.n_tiles;
-    const int NC = (a.KS + KC - 1) / KC;                       // chunks over the whole K
+    // Clamping instead of guarding is exact because: the packed weight has KS % 8 == 0 (zero-padded
+    // k-steps, every chunk whole); surplus waves redo the last tile and skip the store; surplus X
+    // rows / lanes duplicate valid chunks (identical bytes rewritten); X columns beyond Kx meet
+    // zero weights.
+    int tl[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tl[j] = min(tile0 + j, a.n_tiles - 1);
+    const int NC = a.KS / KC;                                  // chunks over the whole (padded) K
     const int c0 = (int)(((long)blockIdx.y * NC) / a.S), c1 = (int)(((long)(blockIdx.y + 1) * NC) / a.S);
 
     f32x4 acc[MT][NT];
@@ -50,44 +64,33 @@ __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 wA[KC][NT], wB[KC][NT];
+    bf16x8 wA[KC][NT], wB[KC][NT], wC[KC][NT];
     bf16x8 xr[C::XLD];
 
     auto load_w = [&](bf16x8 (&w)[KC][NT], int c) {
         const int ks0 = c * KC;
 #pragma unroll
-        for (int i = 0; i < KC; ++i) {
+        for (int i = 0; i < KC; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int ks = ks0 + i, t = tile0 + j;
-                if (wave_active && ks < a.KS && t < a.n_tiles)
-                    w[i][j] = __builtin_nontemporal_load(&a.Wp[((long)t * a.KS + ks) * 64 + lane]);
-                else
-                    w[i][j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
+            for (int j = 0; j < NT; ++j)
+                w[i][j] = __builtin_nontemporal_load(&a.Wp[((long)tl[j] * a.KS + (ks0 + i)) * 64 + lane]);
     };
     auto stage_load = [&](int c) {
         const int kbase = c * KC * 32;
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
-            const int idx = tid + i * C::THREADS;
-            int row = idx / (KC * 4), cc = idx % (KC * 4);
-            if (row > a.M - 1) row = a.M - 1;                   // padded rows: finite duplicates, never stored
-            const int k = kbase + cc * 8;
-            if (idx < C::XCH && k < a.KS * 32)
-                xr[i] = *reinterpret_cast<const bf16x8*>(a.X + (long)row * a.ldx + k);
-            else
-                xr[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            const int idx = min(tid + i * C::THREADS, C::XCH - 1);
+            const int row = min(idx / (KC * 4), a.M - 1);
+            const int k = min(kbase + (idx % (KC * 4)) * 8, a.Kx - 8);
+            xr[i] = *reinterpret_cast<const bf16x8*>(a.X + (long)row * a.ldx + k);
         }
     };
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < C::XLD; ++i) {
-            const int idx = tid + i * C::THREADS;
+            const int idx = min(tid + i * C::THREADS, C::XCH - 1);
             const int row = idx / (KC * 4), cc = idx % (KC * 4);
-            if (idx < C::XCH)
-                *reinterpret_cast<bf16x8*>(xs + buf * C::BUF + row * C::STRIDE + cc * 8) = xr[i];
+            *reinterpret_cast<bf16x8*>(xs + buf * C::BUF + row * C::STRIDE + cc * 8) = xr[i];
         }
     };
     auto compute = [&](bf16x8 (&w)[KC][NT], int buf) {
@@ -102,26 +105,53 @@ __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
             }
         }
     };
+    // one steady-state step: chunk c computes from WCUR, chunk c+2 starts loading into WNEW
+#define WS_STEP(WCUR, WNEW, BUFX)                  \
+    stage_load(c + 1);                             \
+    __builtin_amdgcn_sched_barrier(0);             \
+    load_w(WNEW, c + 2);                           \
+    __builtin_amdgcn_sched_barrier(0);             \
+    compute(WCUR, (BUFX));                         \
+    stage_store((BUFX) ^ 1);                       \
+    __syncthreads();                               \
+    ++c;
 
-    if (c0 < c1) {
+    const int n = c1 - c0;
+    if (n > 0) {
         stage_load(c0);
         load_w(wA, c0);
+        if (n > 1) load_w(wB, c0 + 1);
         stage_store(0);
         __syncthreads();
-        for (int c = c0; c < c1; c += 2) {
-            const bool n1 = (c + 1) < c1;
-            if (n1) { stage_load(c + 1); load_w(wB, c + 1); }
-            compute(wA, 0);
-            if (n1) stage_store(1);
+        int c = c0, buf = 0;
+        const int steady = n > 2 ? n - 2 : 0;                   // steps that prefetch chunk c+2
+        const int pre = steady % 3;
+        for (int i = 0; i < pre; ++i) {                         // remainder, rotate-by-copy form
+            WS_STEP(wA, wC, buf)
+#pragma unroll
+            for (int ii = 0; ii < KC; ++ii)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { wA[ii][j] = wB[ii][j]; wB[ii][j] = wC[ii][j]; }
+            buf ^= 1;
+        }
+        for (int g = steady / 3; g > 0; --g) {                  // straight-line group of 3 steps
+            WS_STEP(wA, wC, buf)
+            WS_STEP(wB, wA, buf ^ 1)
+            WS_STEP(wC, wB, buf)
+            buf ^= 1;
+        }
+        // fixed tail: current = wA, next (if any) = wB
+        if (n > 1) {
+            stage_load(c + 1);
+            compute(wA, buf);
+            stage_store(buf ^ 1);
             __syncthreads();
-            if (!n1) break;
-            const bool n2 = (c + 2) < c1;
-            if (n2) { stage_load(c + 2); load_w(wA, c + 2); }
-            compute(wB, 1);
-            if (n2) stage_store(0);
-            __syncthreads();
+            compute(wB, buf ^ 1);
+        } else {
+            compute(wA, buf);
         }
     }
+#undef WS_STEP
     if (!wave_active) return;
 
     // ---- epilogue: acc[m][j][e] <-> row m*16 + r16, column (tile0+j)*16 + q*4 + e
@@ -195,6 +225,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Repack W[N][K] (row-major, ld = ldw) into fragment order.  dst tile index = nt*tile_stride +
 // tile_off lets the caller interleave several matrices (gate/up pairs, q|k|v concatenation).
+// KS may exceed ceil(K/32): the extra k-steps are zero-filled.
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_w_kernel(const bf16* __restrict__ W, int N, int K, int ldw, bf16x8* __restrict__ Wp,
                               int KS, int n_tiles_src, int tile_stride, int tile_off) {
@@ -233,42 +264,44 @@ static thread_local int g_wpb = 4;      // waves per workgroup for the next disp
 
 template <int MT, int NT, int KC, int EPI>
 static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
-    if constexpr (MT <= 4) {            // the 2-wave variant exists for the single-stream shapes
+    if constexpr (MT <= 4) {            // 2- and 8-wave variants exist for the single-stream shapes
         if (g_wpb == 2) return launch_ws_w<MT, NT, KC, EPI, 2>(a, st);
+        if (g_wpb == 8) return launch_ws_w<MT, NT, KC, EPI, 8>(a, st);
     }
     return launch_ws_w<MT, NT, KC, EPI, 4>(a, st);
 }
 
 template <int NT, int EPI>
 static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
-    // KC (k-steps of 32 per pipeline chunk) shrinks as the accumulator tile grows so that two
+    // KC (k-steps of 32 per pipeline chunk) shrinks as the accumulator tile grows so that three
     // weight register sets + accumulators stay under 256 VGPRs (2 waves/SIMD, no spills).
+    // aha_api.hip:pick_split mirrors this table.
     const int mt = ceil_div(a.M, 16);
     if constexpr (NT == 1) {
         if (mt <= 1) return launch_ws<1, 1, 8, EPI>(a, st);
         if (mt <= 2) return launch_ws<2, 1, 8, EPI>(a, st);
         if (mt <= 3) return launch_ws<3, 1, 8, EPI>(a, st);
-        if (mt <= 4) return launch_ws<4, 1, 8, EPI>(a, st);
-        if (mt <= 6) return launch_ws<6, 1, 4, EPI>(a, st);
-        if (mt <= 8) return launch_ws<8, 1, 4, EPI>(a, st);
-        if (mt <= 12) return launch_ws<12, 1, 2, EPI>(a, st);
-        if (mt <= 16) return launch_ws<16, 1, 2, EPI>(a, st);
+        if (mt <= 4) return launch_ws<4, 1, 4, EPI>(a, st);
+        if (mt <= 6) return launch_ws<6, 1, 2, EPI>(a, st);
+        if (mt <= 8) return launch_ws<8, 1, 2, EPI>(a, st);
+        if (mt <= 12) return launch_ws<12, 1, 1, EPI>(a, st);
+        if (mt <= 16) return launch_ws<16, 1, 1, EPI>(a, st);
     } else {
-        if (mt <= 1) return launch_ws<1, 2, 8, EPI>(a, st);
+        if (mt <= 1) return launch_ws<1, 2, 4, EPI>(a, st);
         if (mt <= 2) return launch_ws<2, 2, 4, EPI>(a, st);
         if (mt <= 3) return launch_ws<3, 2, 4, EPI>(a, st);
         if (mt <= 4) return launch_ws<4, 2, 4, EPI>(a, st);
         if (mt <= 6) return launch_ws<6, 2, 2, EPI>(a, st);
         if (mt <= 8) return launch_ws<8, 2, 2, EPI>(a, st);
     }
-    return hipErrorInvalidValue;               // caller falls back to the tiled GEMM
+    return hipErrorInvalidValue;               // caller chunks M
 }
 
-// Largest M each epilogue supports here (the host routes bigger M to gemm_tile).
+// Largest M each epilogue supports in one launch (the host loops over row chunks beyond it).
 extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 128 : 256; }
 
 extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
-    g_wpb = (wpb == 2) ? 2 : 4;
+    g_wpb = (wpb == 2 || wpb == 8) ? wpb : 4;
     switch (epi) {
         case EPI_PARTIAL: return dispatch_mt<1, EPI_PARTIAL>(*a, st);
         case EPI_BF16: return dispatch_mt<1, EPI_BF16>(*a, st);

@@ -1,0 +1,86 @@
+// Calibration: how fast can gfx950 stream ~272 MB of weights into registers, by access pattern?
+//   A: wave-private sequential streams (layout [wave][step][1 KiB])  - gemm_ws's current layout
+//   B: step-major (layout [step][wave][1 KiB]): co-running waves read adjacent memory
+//   C: plain grid-stride 16-B loads over the whole buffer
+// hipcc --offload-arch=gfx950 -O3 -o stream_bench stream_bench.hip && ./stream_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int U, bool NT_>
+__device__ __forceinline__ u32x4 ld(const u32x4* p) { return NT_ ? __builtin_nontemporal_load(p) : *p; }
+
+// waves = gridDim.x * (blockDim.x/64); each wave reads `steps` blocks of 1 KiB
+template <int U, bool STEP_MAJOR, bool NT_>
+__global__ void stream_k(const u32x4* __restrict__ w, int steps, unsigned* out) {
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * (blockDim.x >> 6);
+    u32x4 acc = {0, 0, 0, 0};
+    for (int s0 = 0; s0 < steps; s0 += U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long blk = STEP_MAJOR ? (long)(s0 + u) * nw + wave : (long)wave * steps + (s0 + u);
+            v[u] = ld<U, NT_>(w + blk * 64 + lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+template <bool NT_>
+__global__ void gridstride_k(const u32x4* __restrict__ w, long n16, unsigned* out) {
+    u32x4 acc = {0, 0, 0, 0};
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 a = ld<1, NT_>(w + i), b = ld<1, NT_>(w + i + stride), c = ld<1, NT_>(w + i + 2 * stride), d = ld<1, NT_>(w + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n16; i += stride) acc ^= ld<1, NT_>(w + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+int main() {
+    const long layer = 2368L * 112 * 1024;           // gate/up of Qwen2-7B: 2368 tiles x 112 k-steps x 1 KiB
+    const int nl = 14;                               // rotate over 3.8 GB so nothing is cache-resident
+    char* buf; unsigned* out;
+    hipMalloc(&buf, layer * nl + (4L << 20));   // slack: no launch may read past the end hipMalloc(&out, 4);
+    hipMemset(buf, 1, layer * nl);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch) {
+        for (int i = 0; i < 3; ++i) launch((const u32x4*)(buf + (i % nl) * layer));
+        hipDeviceSynchronize();
+        float best = 1e9, tot = 0;
+        for (int i = 0; i < nl; ++i) {
+            hipEventRecord(e0); launch((const u32x4*)(buf + i * layer)); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best; tot += ms;
+        }
+        printf("%-44s avg %.1f us  %.2f TB/s   best %.1f us %.2f TB/s\n", name, tot / nl * 1e3, layer / (tot / nl * 1e-3) / 1e12, best * 1e3, layer / (best * 1e-3) / 1e12);
+    };
+    const long blocks = layer / 1024;                // 1 KiB blocks
+    for (int wpb : {4, 8}) {
+        for (int waves : {1184, 2368, 4736}) {
+            const int steps = (int)(blocks / waves);
+            if (steps % 8 != 0 || steps * (long)waves != blocks) continue;
+            char n[128];
+            snprintf(n, 128, "A wave-private seq  waves=%d wpb=%d U=8 nt", waves, wpb);
+            run(n, [&](const u32x4* p) { hipLaunchKernelGGL((stream_k<8, false, true>), dim3(waves / wpb), dim3(64 * wpb), 0, 0, p, steps, out); });
+            snprintf(n, 128, "B step-major        waves=%d wpb=%d U=8 nt", waves, wpb);
+            run(n, [&](const u32x4* p) { hipLaunchKernelGGL((stream_k<8, true, true>), dim3(waves / wpb), dim3(64 * wpb), 0, 0, p, steps, out); });
+            if (steps % 16 != 0 || steps * (long)waves != blocks) continue;   // unrolled loads must stay inside the layer
+            snprintf(n, 128, "A wave-private seq  waves=%d wpb=%d U=16 nt", waves, wpb);
+            run(n, [&](const u32x4* p) { hipLaunchKernelGGL((stream_k<16, false, true>), dim3(waves / wpb), dim3(64 * wpb), 0, 0, p, steps, out); });
+            snprintf(n, 128, "B step-major        waves=%d wpb=%d U=16 nt", waves, wpb);
+            run(n, [&](const u32x4* p) { hipLaunchKernelGGL((stream_k<16, true, true>), dim3(waves / wpb), dim3(64 * wpb), 0, 0, p, steps, out); });
+        }
+    }
+    run("A waves=1184 wpb=4 U=8 plain loads", [&](const u32x4* p) { hipLaunchKernelGGL((stream_k<8, false, false>), dim3(296), dim3(256), 0, 0, p, (int)(blocks / 1184), out); });
+    for (int g : {1024, 2048, 4096}) {
+        char n[128]; snprintf(n, 128, "C grid-stride float4 grid=%d x256 nt", g);
+        run(n, [&](const u32x4* p) { hipLaunchKernelGGL((gridstride_k<true>), dim3(g), dim3(256), 0, 0, p, layer / 16, out); });
+    }
+    run("C grid-stride float4 grid=2048 x256 plain", [&](const u32x4* p) { hipLaunchKernelGGL((gridstride_k<false>), dim3(2048), dim3(256), 0, 0, p, layer / 16, out); });
+    return 0;
+}
