@@ -1,0 +1,383 @@
+"""Stream drivers with the reference's API surface, on top of the HIP runtime.
+
+  LiveInferForBenchmark  <- test/inference.py:38-348
+  LiveInferForDemo       <- test/live_infer_for_video.py:80-228
+  round_numbers          <- test/inference.py:359-375
+
+Same method names, argument meaning, attributes and `debug_data_list` schema
+(`{time, informative_score, relevance_score, uncertainty_score}`), so code written against the
+reference's drivers runs against these.  Differences, all on purpose:
+  * the model is an `aha_amd.runtime.Runtime` (weights already on the GPU) instead of
+    `build_model_and_tokenizer` (needs network); pass `runtime=` or `cfg=`+`weights=`;
+  * frames enter as uint8 and the preprocess is fused into the patch gather on the GPU;
+  * frame embeddings stay in HBM (the reference bounces every embedding through host memory,
+    test/inference.py:185,213) and each frame costs ONE 12-byte D2H copy instead of three `.item()`s;
+  * `inference()` returns the response list (the reference's `return` is commented out, :348).
+"""
+from __future__ import annotations
+
+import collections
+import math
+from dataclasses import asdict
+from typing import List, Optional
+
+import torch
+
+from .arguments import LiveTestArguments
+from .config import LiveConfig
+from .runtime import Runtime, Stream
+from .tokenization import SyntheticChatTokenizer
+
+
+def truncate_sig(x, sig=3):
+    if x == 0:
+        return 0
+    return float(f"{x:.{sig}g}")
+
+
+def round_numbers(data, n):
+    if isinstance(data, list):
+        return [round_numbers(d, n) for d in data]
+    elif isinstance(data, dict):
+        return {k: round_numbers(v, n) for k, v in data.items()}
+    elif isinstance(data, float):
+        if abs(data) <= 10 ** (-n):
+            return truncate_sig(data, n)
+        else:
+            return round(data, n)
+    return data
+
+
+class LiveInferForBenchmark:
+    def __init__(self, args: LiveTestArguments, peft_model_id=None, sink_cache=False, alt_cache="default_sink", *,
+                 runtime: Optional[Runtime] = None, cfg: Optional[LiveConfig] = None, weights=None, tokenizer=None,
+                 device: str = "cuda:0", window_length: int = 2048, num_sink_tokens: int = 32,
+                 attn_semantics: str = "trailing") -> None:
+        assert not (args.bf16 and args.fp16), "only one of --bf16 true and --fp16 true can be set"
+        self.sink_cache = sink_cache
+        self.alt_cache = alt_cache
+        self.peft_model_id = "aha_weights" if not peft_model_id else peft_model_id
+        self.torch_dtype = torch.bfloat16
+        if runtime is None:
+            if cfg is None or weights is None:
+                raise ValueError("pass runtime= or cfg= and weights= (there is no checkpoint download offline)")
+            runtime = Runtime(cfg, weights, device=device)
+        self.model = runtime                       # plays the role of self.model in the reference
+        self.rt = runtime
+        self.cfg = runtime.cfg
+        self.device = runtime.device
+        self.tokenizer = tokenizer or SyntheticChatTokenizer(self.cfg.lm.vocab_size)
+        self._window_length, self._num_sink_tokens, self._attn_semantics = window_length, num_sink_tokens, attn_semantics
+
+        # visual
+        self.hidden_size = self.cfg.lm.hidden_size
+        if args.frame_fps > 0:
+            self.set_fps(args.frame_fps)
+        self.frame_resolution = self.cfg.frame_resolution
+        self.frame_num_tokens = self.cfg.frame_num_tokens
+
+        self.uncertainty_wait_threshold = args.uncertainty_wait_threshold
+        self.max_wait_frames = args.max_wait_frames
+
+        # generation
+        self.system_prompt = args.system_prompt
+        self.max_new_tokens = 200                                  # inplace_output_ids is [1,200] (test/inference.py:73)
+        self.stream_end_prob_threshold = args.stream_end_prob_threshold
+        self.response_min_interval_frames = args.response_min_interval_frames
+        self.threshold_z = args.threshold_z
+        self.first_n_frames_no_generate = args.first_n_frames_no_generate
+        self.running_list_length = args.running_list_length
+        self.stream_end_score_sum_threshold = args.stream_end_score_sum_threshold
+        self.score_heads = args.score_heads.split(",")
+        self.consecutive_n_frames_threshold = args.consecutive_n_frames_threshold
+        n_set = (int(self.threshold_z is not None) + int(self.stream_end_prob_threshold is not None)
+                 + int(self.stream_end_score_sum_threshold is not None))
+        if n_set != 1:
+            raise ValueError(
+                "only one of --stream_end_prob_threshold, --threshold_z and --stream_end_score_sum_threshold can be set. "
+                f"However, they are: {self.stream_end_prob_threshold}, {self.threshold_z}, {self.stream_end_score_sum_threshold}")
+        if self.threshold_z is not None and self.first_n_frames_no_generate is None:
+            raise ValueError("--first_n_frames_no_generate must be set when --threshold_z is set")
+        self.remove_assistant_turns = args.remove_assistant_turns
+        self.eos_token_id = getattr(self.tokenizer, "eos_token_id", 0)
+        self._start_ids = self.tokenizer.apply_chat_template(
+            [{"role": "system", "content": self.system_prompt}], return_tensors="pt").to(self.device)
+        self._added_stream_prompt_ids = self.tokenizer.apply_chat_template(
+            [{}], add_stream_prompt=True, return_tensors="pt").to(self.device)
+        self._added_stream_generation_ids = self.tokenizer.apply_chat_template(
+            [{}], add_stream_generation_prompt=True, return_tensors="pt").to(self.device)
+        self.repetition_penalty = args.repetition_penalty
+        self.past_key_values: Optional[Stream] = None
+        self.reset()
+
+    # ---- test/inference.py:101-110 ---------------------------------------------------------------
+    def set_fps(self, fps=None, frame_interval=None):
+        assert fps is not None or frame_interval is not None
+        assert not (fps is not None and frame_interval is not None)
+        if fps is not None:
+            self.frame_fps = fps
+            self.frame_interval = 1 / self.frame_fps
+        else:
+            self.frame_interval = frame_interval
+            self.frame_fps = 1 / self.frame_interval
+
+    # ---- test/inference.py:112-130 ---------------------------------------------------------------
+    def reset(self):
+        self.query_queue = collections.deque()
+        self.frame_embeds_queue = collections.deque()
+        self.video_time = 0
+        self.frame_idx = 0
+        self.last_role = "system"
+        self.video_tensor = None
+        self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        self._init_cache(self._window_length, self._num_sink_tokens)
+        self.first_query_processed = False
+        self.debug_data_list = list()
+        self.generated_token_ids = list()
+        self.init_vision_time = False
+        self.num_frames_no_reply = 0
+        self.stream_end_prob_list = list()
+        self.stream_end_score_sum = 0
+        self.consecutive_n_frames = 0
+
+    # ---- test/inference.py:133-155 ---------------------------------------------------------------
+    def _init_cache(self, window_length=2048, num_sink_tokens=32, instruction_ids=None):
+        if instruction_ids is None:
+            instruction_ids = self._start_ids
+        num_instruction_tokens = instruction_ids.shape[1]
+        local_window_length = window_length + num_sink_tokens - num_instruction_tokens
+        if self.sink_cache:
+            spec = ("default_sink", local_window_length, num_instruction_tokens)
+        elif self.alt_cache and self.alt_cache == "default_sink":
+            spec = ("default_sink", window_length, num_sink_tokens)
+        elif self.alt_cache and self.alt_cache == "sliding_window":
+            spec = ("sliding_window", window_length, 0)
+        elif self.alt_cache and self.alt_cache == "static":
+            spec = ("static", window_length, 0)
+        else:
+            spec = (None, window_length, 0)
+        old = self.past_key_values
+        if old is not None and getattr(old, "_spec", None) == spec and old.handle is not None:
+            old.reset()                              # same policy: reuse the preallocated KV buffers
+            return
+        if old is not None:
+            old.close()
+        self.past_key_values = self.rt.open_stream(spec[0], spec[1], spec[2], attn_semantics=self._attn_semantics)
+        self.past_key_values._spec = spec
+
+    # ---- test/inference.py:169-187 ---------------------------------------------------------------
+    @torch.no_grad()
+    def input_video_stream(self, video_frames: torch.Tensor):
+        """video_frames: uint8 [T,3,S,S] RGB (what load_video_for_testing returns)."""
+        assert video_frames.dtype == torch.uint8
+        video_frames = video_frames.to(self.device)
+        batch_size = 32
+        for batch_i in range(0, math.ceil(len(video_frames) / batch_size)):
+            batch = video_frames[batch_i * batch_size: batch_i * batch_size + batch_size]
+            frame_embeds = self.rt.visual_embed(batch).split(self.frame_num_tokens)
+            self.frame_embeds_queue.extend(
+                [((r + batch_i * batch_size) / self.frame_fps, f) for r, f in enumerate(frame_embeds)])
+
+    # ---- test/inference.py:189-192 ---------------------------------------------------------------
+    def input_query_stream(self, conversation):
+        for turn in conversation:
+            if turn["role"] == "user":
+                self.query_queue.append((turn["time"], turn["content"]))
+
+    # ---- test/inference.py:196-229 ---------------------------------------------------------------
+    def _encode_frame(self):
+        """returns: ({informative_score, relevance_score}, uncertainty_score)"""
+        if not self.frame_embeds_queue:
+            return None, None
+        video_time, frame_embeds = self.frame_embeds_queue.popleft()
+        if not self.init_vision_time:
+            self.last_ids = self._start_ids
+            self.init_vision_time = True
+        elif self.last_role == "assistant" and not self.remove_assistant_turns:
+            self.last_ids = torch.cat([self.last_ids, self._added_stream_prompt_ids], dim=1)
+        else:
+            self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        inputs_embeds = torch.cat([
+            self.rt.embed_tokens(self.last_ids).view(1, -1, self.hidden_size),
+            frame_embeds.view(1, -1, self.hidden_size)], dim=1)
+        scores = self.rt.lm_step([self.past_key_values], inputs_embeds)
+        self.frame_idx += 1
+        self.num_frames_no_reply += 1
+        s = scores[0].tolist()                       # one 12-byte D2H copy per frame
+        self.last_role = "stream"
+        return {"informative_score": s[0], "relevance_score": s[1]}, s[2]
+
+    # ---- test/inference.py:231-262 ---------------------------------------------------------------
+    def _encode_query(self):
+        query_time, query = self.query_queue.popleft()
+        query_ids = self.tokenizer.apply_chat_template(
+            [{"role": "user", "content": query}], add_stream_query_prompt=self.last_role == "stream",
+            add_stream_prompt=True, return_tensors="pt").to(self.device)
+        self.last_ids = query_ids
+        inputs_embeds = self.rt.embed_tokens(self.last_ids).view(1, -1, self.hidden_size)
+        self.rt.lm_step([self.past_key_values], inputs_embeds)
+        _, am = self.rt.logits_last(1, want_logits=False)
+        self.last_ids = am.view(1, 1)
+        self.last_role = "user"
+
+    # ---- models/modeling_live.py:64-90 (fast_greedy_generate) + test/inference.py:264-281 ----------
+    def _generate_response(self):
+        self.last_ids = self._added_stream_generation_ids
+        inputs_embeds = self.rt.embed_tokens(self.last_ids).view(1, -1, self.hidden_size)
+        output_ids: List[int] = []
+        for _ in range(self.max_new_tokens):
+            self.rt.lm_step([self.past_key_values], inputs_embeds)
+            if self.repetition_penalty is not None:
+                logits, _ = self.rt.logits_last(1)
+                if len(self.generated_token_ids) > 0:    # RepetitionPenaltyLogitsProcessor
+                    idx = torch.tensor(self.generated_token_ids, device=self.device)[None]
+                    sc = torch.gather(logits, 1, idx)
+                    sc = torch.where(sc < 0, sc * self.repetition_penalty, sc / self.repetition_penalty)
+                    logits = logits.scatter(1, idx, sc)
+                tok = int(logits.argmax(dim=-1).item())
+                if tok != self.eos_token_id:             # special tokens should not be penalized
+                    self.generated_token_ids.append(tok)
+            else:
+                _, am = self.rt.logits_last(1, want_logits=False)
+                tok = int(am.item())
+            output_ids.append(tok)
+            if tok == self.eos_token_id:
+                break
+            inputs_embeds = self.rt.embed_tokens(torch.tensor([[tok]], device=self.device)).view(1, 1, self.hidden_size)
+        if not self.remove_assistant_turns:
+            self.last_ids = torch.tensor([[output_ids[-1]]], device=self.device)
+        else:
+            self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        response = self.tokenizer.decode(output_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+        self.num_frames_no_reply = 0
+        self.last_role = "assistant"
+        return response
+
+    # ---- test/inference.py:283-335 ---------------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, verbose=False, total=None):
+        model_response_list = [{"time": q[0], "content": q[1], "role": "user"} for q in self.query_queue]
+        while self.frame_embeds_queue:
+            # 1. check if a user query is at current time
+            if self.query_queue and self.video_time >= self.query_queue[0][0]:
+                self._encode_query()
+            # 2. input a frame, and update the scores list
+            video_scores, uncertainty_score = self._encode_frame()
+            self.debug_data_list.append(dict(time=self.video_time, **video_scores, uncertainty_score=uncertainty_score))
+            # 3. check the scores, if need to generate a response
+            need_response = False
+            stream_end_score = sum([v for k, v in video_scores.items() if k in self.score_heads])
+            self.stream_end_prob_list.append(stream_end_score)
+            self.stream_end_score_sum += stream_end_score
+            if isinstance(self.running_list_length, int) and self.running_list_length > 0:
+                self.stream_end_prob_list = self.stream_end_prob_list[-self.running_list_length:]
+            if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
+                need_response = True
+                self.stream_end_score_sum = 0
+            if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
+                need_response = True
+            # 4. record the responses
+            if need_response:
+                response = self._generate_response()
+                model_response_list.append({"time": self.video_time, "content": response, "role": "assistant"})
+                self.num_frames_no_reply = 0
+                self.consecutive_n_frames = 0
+            # 5. update the video time
+            self.video_time += 1 / self.frame_fps
+            if verbose and self.frame_idx % 50 == 0:
+                print(f"frame {self.frame_idx}" + (f"/{total}" if total else "") + f" {self.video_time:.2f}s", flush=True)
+        return sorted(model_response_list, key=lambda x: x["time"])
+
+
+def pad_to_square(frame_u8: torch.Tensor, output_resolution: int) -> torch.Tensor:
+    """Aspect-preserving resize + centred zero pad of one uint8 [3,h,w] frame, the geometry of
+    load_video / load_one_frame (test/live_infer_for_video.py:49-71,108-121)."""
+    _, h, w = frame_u8.shape
+    if w > h:
+        new_w, new_h = output_resolution, int((h / w) * output_resolution)
+    else:
+        new_h, new_w = output_resolution, int((w / h) * output_resolution)
+    x = torch.nn.functional.interpolate(frame_u8[None].float(), size=(new_h, new_w), mode="bilinear", align_corners=False)
+    x = x.round().clamp(0, 255).to(torch.uint8)[0]
+    top, left = (output_resolution - new_h) // 2, (output_resolution - new_w) // 2
+    canvas = torch.zeros((3, output_resolution, output_resolution), dtype=torch.uint8, device=frame_u8.device)
+    canvas[:, top:top + new_h, left:left + new_w] = x
+    return canvas
+
+
+class LiveInferForDemo(LiveInferForBenchmark):
+    def __init__(self, args, peft_model_id=None, query=None, **kw):
+        super().__init__(args, peft_model_id, **kw)
+        self.system_prompt = "A multimodal AI assistant is helping users with some activities. \
+        Below is their conversation, interleaved with the list of video frames received by the assistant."
+
+    # ---- test/live_infer_for_video.py:98-128 -----------------------------------------------------------
+    def load_one_frame(self, frame_path=None, frame_object=None):
+        """frame_object: uint8 tensor [3,h,w] (or a PIL image / HxWx3 array); frame_path: an image file
+        (needs PIL).  Resize + pad to frame_resolution, encode ONE frame, queue its embedding."""
+        assert frame_path is not None or frame_object is not None
+        if frame_object is None:
+            from PIL import Image            # optional dependency, only for file input
+            frame_object = Image.open(frame_path)
+        if not torch.is_tensor(frame_object):
+            import numpy as np
+            frame_object = torch.from_numpy(np.array(frame_object)).permute(2, 0, 1)
+        canvas = pad_to_square(frame_object.to(self.device), self.frame_resolution)
+        frame_embeds = self.rt.visual_embed(canvas[None]).split(self.frame_num_tokens)
+        self.frame_embeds_queue.append((self.video_time, frame_embeds[0]))
+
+    # ---- test/live_infer_for_video.py:135-176 ----------------------------------------------------------
+    def input_one_frame(self):
+        video_scores, uncertainty_scores = self._encode_frame()
+        ret = dict(frame_idx=self.frame_idx, time=round(self.video_time, 1), uncertainty_score=uncertainty_scores,
+                   **video_scores)
+        need_response = False
+        stream_end_score = sum([v for k, v in video_scores.items() if k in self.score_heads])
+        self.stream_end_prob_list.append(stream_end_score)
+        self.stream_end_score_sum += stream_end_score
+        if isinstance(self.running_list_length, int) and self.running_list_length > 0:
+            self.stream_end_prob_list = self.stream_end_prob_list[-self.running_list_length:]
+        if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
+            need_response = True
+            self.stream_end_score_sum = 0
+        if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
+            need_response = True
+        if need_response:
+            response = self._generate_response()
+            self.num_frames_no_reply = 0
+            self.consecutive_n_frames = 0
+        else:
+            response = None
+        ret["response"] = response
+        self.video_time += 1 / self.frame_fps
+        return ret
+
+    # ---- test/live_infer_for_video.py:179-192 ----------------------------------------------------------
+    def input_video(self, video_frames, query, fps=None):
+        """video_frames: uint8 [T,3,S,S] already decoded/resized (decoding with cv2 is frame ingest,
+        SURVEY.md 8f item 3).  Returns (results, model_response_list) like the reference."""
+        conversation = [{"role": "system", "content": self.system_prompt}, {"role": "user", "content": query, "time": 0}]
+        self.set_fps(fps=fps or self.frame_fps)
+        self.input_video_stream(video_frames)
+        self.input_query_stream(conversation)
+        model_response_list = self.inference(verbose=False, total=len(video_frames))
+        results = round_numbers(self.debug_data_list, 3)
+        return results, model_response_list
+
+    # ---- test/live_infer_for_video.py:195-228 ----------------------------------------------------------
+    def find_ticks(self, scores, fps, min_separation=10, prominence=0.02, thresh=False, verbose=False):
+        """Savitzky-Golay(15,3) smoothing + find_peaks(height=mean+0.5*std, prominence, distance)."""
+        import numpy as np
+        from scipy.signal import find_peaks, savgol_filter
+        if not isinstance(scores, np.ndarray):
+            scores = np.array(scores)
+        smoothed = savgol_filter(scores, window_length=15, polyorder=3)
+        if not thresh:
+            thresh = smoothed.mean() + 0.5 * smoothed.std()
+        min_separation = 10                       # the reference overrides its own argument (:214)
+        distance = int(min_separation * fps)
+        peaks, _ = find_peaks(smoothed, height=thresh, prominence=prominence, distance=distance)
+        peak_times = peaks / fps
+        if verbose:
+            print("Detected spikes at:", peak_times)
+        return list(peak_times)

@@ -1,0 +1,50 @@
+"""Test helper: a stand-in for aha_amd.runtime.Runtime whose arithmetic is the ORACLE on CPU, so the
+host logic of the drivers (queues, prompts, trigger rules, rounding, sharding) can be tested
+without a GPU.  Lives under tests/ - the product never imports it."""
+import torch
+
+from oracle.cache_policies import make_policy
+from oracle.qwen2_live import OracleLM, frame_scores
+from oracle.vision_tower import OracleVision
+
+
+class _FakeStream:
+    def __init__(self, alt, W, S):
+        self.alt, self.W, self.S = alt, W, S
+        self.handle = object()
+        self.reset()
+
+    def reset(self):
+        self.pol = make_policy(self.alt, self.W, self.S)
+
+    def get_seq_length(self, layer_idx=0):
+        return self.pol.get_seq_length()
+
+    def close(self):
+        self.handle = None
+
+
+class OracleBackedRuntime:
+    def __init__(self, cfg, weights, dtype=torch.float32):
+        self.cfg, self.device = cfg, torch.device("cpu")
+        self.hidden_size, self.frame_num_tokens = cfg.lm.hidden_size, cfg.frame_num_tokens
+        self.lm, self.vis, self.dtype = OracleLM(cfg.lm, weights, dtype), OracleVision(cfg, weights, dtype), dtype
+        self._last = None
+
+    def open_stream(self, alt_cache="default_sink", window_length=2048, num_sink_tokens=32, capacity=None, attn_semantics="trailing"):
+        return _FakeStream(alt_cache, window_length, num_sink_tokens)
+
+    def visual_embed(self, frames_u8):
+        return self.vis.visual_embed(frames_u8)
+
+    def embed_tokens(self, ids):
+        return self.lm.embed_tokens(ids.view(-1))
+
+    def lm_step(self, streams, embeds, want_raw=False, want_hidden=False):
+        outs = [self.lm.step(embeds[b:b + 1].to(self.dtype), s.pol, want_logits=True) for b, s in enumerate(streams)]
+        self._last = outs
+        return torch.cat([frame_scores(o) for o in outs], 0)
+
+    def logits_last(self, B, want_logits=True):
+        lg = torch.cat([o["logits"][:, -1] for o in self._last], 0)
+        return (lg if want_logits else None), lg.argmax(-1)

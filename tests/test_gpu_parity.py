@@ -198,3 +198,177 @@ def test_errors_are_reported_not_crashed(tiny):
     with pytest.raises(AhaError):
         rt.lm_step([st, st], torch.zeros(2, 4, cfg.lm.hidden_size, dtype=torch.bfloat16, device="cuda"))
     st.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# drivers / model API on the GPU
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("alt_cache", ["default_sink", "static"])
+def test_driver_on_gpu_matches_oracle_driver(tiny, alt_cache):
+    from aha_amd.arguments import LiveTestArguments
+    from aha_amd.live_infer import LiveInferForBenchmark
+    from aha_amd.tokenization import SyntheticChatTokenizer
+    from oracle.live_driver import OracleLiveInfer
+    cfg, w, rt = tiny
+    tok = SyntheticChatTokenizer(cfg.lm.vocab_size)
+    args = LiveTestArguments(frame_fps=1, stream_end_prob_threshold=9.0)
+    drv = LiveInferForBenchmark(args, alt_cache=alt_cache, runtime=rt, tokenizer=tok, window_length=96, num_sink_tokens=4)
+    kw = dict(alt_cache=alt_cache, window_length=96, num_sink_tokens=4, frame_fps=1,
+              start_ids=tok.apply_chat_template([{"role": "system", "content": args.system_prompt}]),
+              stream_prompt_ids=tok.apply_chat_template([{}], add_stream_prompt=True),
+              stream_generation_ids=tok.apply_chat_template([{}], add_stream_generation_prompt=True),
+              stream_end_prob_threshold=9.0)
+    ob, o32 = OracleLiveInfer(cfg, w, dtype=torch.bfloat16, **kw), OracleLiveInfer(cfg, w, dtype=torch.float32, **kw)
+    frames = make_frames(20, cfg.vision.image_size, seed=6)
+    q = "tell me when something happens"
+    qids = tok.apply_chat_template([{"role": "user", "content": q}], add_stream_prompt=True)
+    drv.input_video_stream(frames)
+    drv.input_query_stream([{"role": "user", "content": q, "time": 0}])
+    drv.inference()
+    for o in (ob, o32):
+        o.input_video_stream(frames)
+        o.input_query_stream([{"role": "user", "time": 0, "ids": qids}])
+        o.inference()
+    keys = ("informative_score", "relevance_score")
+    band = max(abs(a[k] - b[k]) for a, b in zip(ob.debug_data_list, o32.debug_data_list) for k in keys)
+    d32 = max(abs(a[k] - b[k]) for a, b in zip(drv.debug_data_list, o32.debug_data_list) for k in keys)
+    assert len(drv.debug_data_list) == 20 and drv.past_key_values.get_seq_length() == ob.past_key_values.get_seq_length()
+    assert [d["time"] for d in drv.debug_data_list] == [d["time"] for d in ob.debug_data_list]
+    assert d32 <= max(SCORE_TOL, 2.0 * band), (d32, band)
+
+
+def test_model_api_forward(tiny):
+    from aha_amd.cache import SinkCache
+    from aha_amd.model import LiveLlavaModel
+    from oracle.cache_policies import SinkPolicy
+    from oracle.qwen2_live import OracleLM
+    cfg, w, rt = tiny
+    model = LiveLlavaModel(rt)
+    cache, oc = SinkCache(window_length=24, num_sink_tokens=4), SinkPolicy(24, 4)
+    o = OracleLM(cfg.lm, w, torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    for T in (9, 6, 6, 6):
+        x = (torch.randn(1, T, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16()
+        out = model(inputs_embeds=x.cuda(), past_key_values=cache, use_cache=True, return_dict=True, max_new_tokens=2048)
+        want = o.step(x, oc, want_logits=True)
+        assert out.past_key_values is cache and cache.get_seq_length() == oc.get_seq_length()
+        assert out.informative_logits.shape == (1, T, 2) and out.uncertainty.shape == (1, T, 1)
+        assert (out.informative_logits.cpu() - want["informative_logits"]).abs().max().item() <= 0.03
+        assert (out.relevance_logits.cpu() - want["relevance_logits"]).abs().max().item() <= 8e-3
+        assert (out.logits.cpu()[:, 0] - want["logits"][:, -1]).abs().max().item() <= 0.08
+    assert cache._seen_tokens == 27 and cache.get_max_cache_shape() == 24
+    ids = torch.tensor([[5, 9, 11]])
+    assert model.get_input_embeddings()(ids.cuda()).shape == (1, 3, cfg.lm.hidden_size)
+
+
+# ---------------------------------------------------------------------------------------------------
+# 7B-wide shapes (the kernels' real tile configurations) at a depth the oracle finishes in seconds
+# ---------------------------------------------------------------------------------------------------
+def _bench_width_cfg(layers):
+    from aha_amd.config import LiveConfig, LMConfig, VisionConfig
+    return LiveConfig(vision=VisionConfig(num_hidden_layers=layers),
+                      lm=LMConfig(num_hidden_layers=layers, vocab_size=4096), name=f"bench{layers}l")
+
+
+def test_7b_wide_two_layer_parity():
+    from oracle.cache_policies import make_policy
+    from oracle.qwen2_live import OracleLM, frame_scores
+    from oracle.vision_tower import OracleVision
+    cfg = _bench_width_cfg(2)
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=128, max_vit_frames=2, max_positions=4096)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    fr = make_frames(2, cfg.vision.image_size, seed=0)
+    ov = OracleVision(cfg, w, torch.bfloat16)
+    want_e = ov.visual_embed(fr).float()
+    got_e = rt.visual_embed(fr.cuda()).float().cpu()
+    assert (got_e - want_e).abs().max().item() <= 0.03 * max(1.0, want_e.abs().max().item())
+    ob, o32 = OracleLM(cfg.lm, w, torch.bfloat16), OracleLM(cfg.lm, w, torch.float32)
+    for policy in ("default_sink", "static"):
+        cb, c32 = make_policy(policy, 128, 8), make_policy(policy, 128, 8)
+        st = rt.open_stream(policy, 128, 8)
+        g = torch.Generator().manual_seed(31)
+        d32 = band = 0.0
+        for T in (20, 71, 36, 36, 36):                   # query, system prompt + frame 0, frames (Tf = 36); 4th step evicts
+            x = (torch.randn(1, T, cfg.lm.hidden_size, generator=g) * 0.3).bfloat16()
+            sb, s32 = _rel_unc(frame_scores(ob.step(x, cb))), _rel_unc(frame_scores(o32.step(x.float(), c32)))
+            gs = _rel_unc(rt.lm_step([st], x.cuda()).cpu())
+            d32, band = max(d32, (gs - s32).abs().max().item()), max(band, (sb - s32).abs().max().item())
+            assert st.get_seq_length() == cb.get_seq_length()
+        assert d32 <= max(SCORE_TOL, 2.0 * band), (policy, d32, band)
+        st.close()
+    rt.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE.json full size (28-layer Qwen2-7B dims + 24-layer ViT-L/14@336): size-independent properties
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def bench_rt():
+    cfg = preset("bench")
+    w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
+    rt = _rt(cfg, w, max_step_tokens=160, max_vit_frames=8)
+    del w
+    torch.cuda.empty_cache()
+    yield cfg, rt
+    rt.close()
+
+
+def test_full_size_static_cache_frames_are_independent(bench_rt):
+    """TrulyStaticCache never changes after its first call, so a frame's scores cannot depend on how
+    many frames came before it (test/static_cache.py:26-36): bit-exact on the full model."""
+    cfg, rt = bench_rt
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    g = torch.Generator().manual_seed(77)
+    prefix = (torch.randn(1, 20, H, generator=g) * 0.1).bfloat16().cuda()
+    fa, fb = [(torch.randn(1, tf, H, generator=g) * 0.1).bfloat16().cuda() for _ in range(2)]
+    s1, s2 = rt.open_stream("static", 2048, 0), rt.open_stream("static", 2048, 0)
+    rt.lm_step([s1], prefix), rt.lm_step([s2], prefix)
+    for _ in range(3):
+        rt.lm_step([s1], fa)
+    a, b = rt.lm_step([s1], fb).cpu(), rt.lm_step([s2], fb).cpu()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert s1.get_seq_length() == s2.get_seq_length() == 20
+    s1.close(), s2.close()
+
+
+def test_full_size_window_policies_equal_growing_cache_until_they_evict(bench_rt):
+    """Before the first eviction SinkCache / SlidingWindowCache are plain appends (test/sink_cache.py
+    :129-132, test/sliding_window_cache.py:33-44): scores must equal the growing cache's bit for bit,
+    through the ring addressing, on the full model; after it they must differ."""
+    cfg, rt = bench_rt
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    g = torch.Generator().manual_seed(78)
+    xs = [(torch.randn(1, tf, H, generator=g) * 0.1).bfloat16().cuda() for _ in range(8)]
+    W = 6 * tf + 10
+    sg, ss, sl = rt.open_stream(None, capacity=1024), rt.open_stream("default_sink", W, 8), rt.open_stream("sliding_window", W, 0)
+    for i, x in enumerate(xs):
+        a, b, c = rt.lm_step([sg], x).cpu(), rt.lm_step([ss], x).cpu(), rt.lm_step([sl], x).cpu()
+        if (i + 1) * tf < W:
+            assert torch.equal(a, b) and torch.equal(a, c), i
+    assert not torch.equal(a, b) and not torch.equal(a, c)
+    assert sg.get_seq_length() == 8 * tf and ss.get_seq_length() == W and sl.get_seq_length() == W
+    for s in (sg, ss, sl):
+        s.close()
+
+
+def test_full_size_batched_streams_and_vit_batches(bench_rt):
+    """Streams never mix: B streams in one step score like each stream alone (different GEMM tile
+    configuration, so to bf16 noise); a ViT batch encodes each frame like a batch of one (bit-exact)."""
+    cfg, rt = bench_rt
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    fr = make_frames(4, cfg.vision.image_size, seed=5).cuda()
+    e4 = rt.visual_embed(fr)
+    e1 = torch.cat([rt.visual_embed(fr[i:i + 1]) for i in range(4)], 0)
+    assert torch.equal(e4, e1) and torch.isfinite(e4.float()).all()
+    emb = e4.view(4, tf, H)
+    solo = [rt.open_stream("default_sink", 2048, 32) for _ in range(3)]
+    both = [rt.open_stream("default_sink", 2048, 32) for _ in range(3)]
+    for step in range(3):
+        x = emb[[step, (step + 1) % 4, (step + 2) % 4]].contiguous()
+        sb = _rel_unc(rt.lm_step(both, x).cpu())
+        for i in range(3):
+            ss = _rel_unc(rt.lm_step([solo[i]], x[i:i + 1]).cpu())
+            assert (ss[0] - sb[i]).abs().max().item() <= 0.02, (step, i)
+    for s in solo + both:
+        s.close()

@@ -1,0 +1,148 @@
+"""CPU tests of the host side: driver logic against the oracle's restatement of the reference
+driver, rounding / peak picking, cache-policy selection, stream sharding over gloo (world 2)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import aha_amd  # noqa: F401
+from aha_amd.arguments import LiveTestArguments
+from aha_amd.config import preset
+from aha_amd.live_infer import LiveInferForBenchmark, LiveInferForDemo, pad_to_square, round_numbers
+from aha_amd.synth import make_frames, make_weights
+from aha_amd.tokenization import SyntheticChatTokenizer
+from oracle.live_driver import OracleLiveInfer, round_numbers as oracle_round
+from oracle_backend import OracleBackedRuntime
+
+
+def _pair(alt_cache, **argkw):
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    tok = SyntheticChatTokenizer(cfg.lm.vocab_size)
+    args = LiveTestArguments(frame_fps=2, **argkw)
+    drv = LiveInferForBenchmark(args, alt_cache=alt_cache, runtime=OracleBackedRuntime(cfg, w), tokenizer=tok,
+                                window_length=96, num_sink_tokens=4)
+    ora = OracleLiveInfer(
+        cfg, w, dtype=torch.float32, alt_cache=alt_cache, window_length=96, num_sink_tokens=4, frame_fps=2,
+        start_ids=tok.apply_chat_template([{"role": "system", "content": args.system_prompt}]),
+        stream_prompt_ids=tok.apply_chat_template([{}], add_stream_prompt=True),
+        stream_generation_ids=tok.apply_chat_template([{}], add_stream_generation_prompt=True),
+        score_heads=args.score_heads, stream_end_prob_threshold=args.stream_end_prob_threshold,
+        stream_end_score_sum_threshold=args.stream_end_score_sum_threshold, running_list_length=args.running_list_length,
+        eos_token_id=tok.eos_token_id, max_new_tokens=6, repetition_penalty=args.repetition_penalty)
+    drv.max_new_tokens = 6
+    return cfg, tok, drv, ora
+
+
+@pytest.mark.parametrize("alt_cache", ["default_sink", "sliding_window", "static", None])
+def test_driver_matches_oracle_driver(alt_cache):
+    cfg, tok, drv, ora = _pair(alt_cache, stream_end_prob_threshold=9.0)      # never respond
+    frames = make_frames(20, cfg.vision.image_size, seed=3)
+    q = "what is happening now?"
+    for d in (drv,):
+        d.input_video_stream(frames)
+        d.input_query_stream([{"role": "user", "content": q, "time": 0}])
+    ora.input_video_stream(frames)
+    qids = tok.apply_chat_template([{"role": "user", "content": q}], add_stream_query_prompt=False, add_stream_prompt=True)
+    ora.input_query_stream([{"role": "user", "time": 0, "ids": qids}])
+    resp = drv.inference()
+    ora.inference()
+    assert len(drv.debug_data_list) == 20 and resp[0]["role"] == "user"
+    for a, b in zip(drv.debug_data_list, ora.debug_data_list):
+        assert set(a) == {"time", "informative_score", "relevance_score", "uncertainty_score"}
+        for k in a:
+            assert a[k] == pytest.approx(b[k], abs=1e-6)
+    assert drv.past_key_values.get_seq_length() == ora.past_key_values.get_seq_length()
+    assert drv.frame_idx == 20 and drv.video_time == pytest.approx(10.0)
+
+
+def test_driver_responses_and_score_sum_rule():
+    cfg, tok, drv, ora = _pair("default_sink", stream_end_score_sum_threshold=2.0, repetition_penalty=1.2)
+    frames = make_frames(8, cfg.vision.image_size, seed=4)
+    drv.input_video_stream(frames)
+    ora.input_video_stream(frames)
+    got = drv.inference()
+    want = ora.inference()
+    assert len(got) == len(want) >= 1                     # the running sum crossed 2.0 at least once
+    for a, b in zip(got, want):
+        assert a["time"] == pytest.approx(b["time"]) and a["role"] == "assistant"
+        assert a["content"] == tok.decode(b["content"])
+    assert drv.last_role in ("assistant", "stream")
+    assert drv.past_key_values.get_seq_length() == ora.past_key_values.get_seq_length()
+
+
+def test_threshold_validation_and_reset():
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32)
+    rt = OracleBackedRuntime(cfg, w)
+    with pytest.raises(ValueError):
+        LiveInferForBenchmark(LiveTestArguments(), runtime=rt)                    # no threshold set
+    with pytest.raises(ValueError):
+        LiveInferForBenchmark(LiveTestArguments(stream_end_prob_threshold=1.0, stream_end_score_sum_threshold=1.0), runtime=rt)
+    d = LiveInferForBenchmark(LiveTestArguments(stream_end_prob_threshold=9.0), alt_cache="static", runtime=rt)
+    assert d.past_key_values.alt == "static"
+    d.input_video_stream(make_frames(2, cfg.vision.image_size))
+    d.inference()
+    d.reset()
+    assert d.video_time == 0 and d.frame_idx == 0 and not d.debug_data_list and d.past_key_values.get_seq_length() == 0
+    d.set_fps(frame_interval=0.25)
+    assert d.frame_fps == 4
+    d2 = LiveInferForBenchmark(LiveTestArguments(stream_end_prob_threshold=9.0), sink_cache=True, runtime=rt)
+    n_sys = d2._start_ids.shape[1]                       # sink_cache=True: system prompt is the sink (test/inference.py:143-147)
+    assert d2.past_key_values.S == n_sys and d2.past_key_values.W == 2048 + 32 - n_sys
+
+
+def test_round_numbers_matches_reference_rule():
+    data = [{"time": 0.5, "a": 0.123456, "b": 0.00012345, "c": 0.0, "n": 3}, [1.23456, -0.0004567]]
+    assert round_numbers(data, 3) == oracle_round(data, 3)
+    assert round_numbers(0.00012345, 3) == 0.000123 and round_numbers(0.123456, 3) == 0.123
+
+
+def test_find_ticks_and_demo_frame_geometry():
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32)
+    demo = LiveInferForDemo(LiveTestArguments(stream_end_prob_threshold=9.0, frame_fps=1), runtime=OracleBackedRuntime(cfg, w))
+    t = np.arange(120)
+    scores = 0.2 + 0.5 * np.exp(-0.5 * ((t - 30) / 3.0) ** 2) + 0.4 * np.exp(-0.5 * ((t - 85) / 4.0) ** 2)
+    assert demo.find_ticks(scores, fps=1) == [30.0, 85.0]
+    assert demo.find_ticks(list(scores), fps=2) == [15.0, 42.5]
+    f = torch.full((3, 20, 40), 200, dtype=torch.uint8)                 # landscape: height padded
+    sq = pad_to_square(f, cfg.frame_resolution)
+    S = cfg.frame_resolution
+    assert sq.shape == (3, S, S) and sq[:, 0].max() == 0 and sq[:, S // 2].min() == 200
+    demo.load_one_frame(frame_object=f)
+    out = demo.input_one_frame()
+    assert set(out) == {"frame_idx", "time", "uncertainty_score", "informative_score", "relevance_score", "response"}
+    assert out["frame_idx"] == 1 and out["response"] is None
+
+
+# ---- multi-process: stream sharding + score all-gather over gloo, world_size 2 -----------------------
+def _rank_main(rank, world, port, n_streams, ret):
+    import torch.distributed as dist
+    from aha_amd.sharding import gather_scores, streams_of_rank
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = streams_of_rank(n_streams, world, rank)
+    F = 4
+    local = torch.stack([torch.stack([torch.tensor([s + 0.1 * f, s + 0.2, -float(s)]) for s in mine]) for f in range(F)]) \
+        if mine else torch.zeros((F, 0, 3))
+    glob = gather_scores(local.float(), n_streams)
+    ret[rank] = glob.numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_streams", [5, 2])
+def test_stream_sharding_allgather_gloo(n_streams):
+    import torch.multiprocessing as mp
+    from aha_amd.sharding import streams_of_rank
+    assert streams_of_rank(5, 2, 0) == [0, 2, 4] and streams_of_rank(5, 2, 1) == [1, 3]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000) + n_streams
+    mp.spawn(_rank_main, args=(2, port, n_streams, ret), nprocs=2, join=True)
+    want = np.stack([np.stack([[s + 0.1 * f, s + 0.2, -float(s)] for s in range(n_streams)]) for f in range(4)]).astype(np.float32)
+    for r in (0, 1):
+        np.testing.assert_allclose(ret[r], want)
