@@ -44,6 +44,19 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be
+    collected from inside the process being measured)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        for k in d["kernels"]:
+            if kernel_prefix in k["kernel"]:
+                return k["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def host_cores():
     """Cores this process may actually use (cgroup quota / affinity), not the machine's core count."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -209,7 +222,10 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None,
                          "avg_launch_us": g_ms / g_n * 1e3 if g_n else None, "launches_timed": g_n,
-                         "algorithmic_bytes_per_launch": g_bytes / g_n if g_n else None, "traffic": None},
+                         "algorithmic_bytes_per_launch": g_bytes / g_n if g_n else None,
+                         "traffic": pmc_traffic("gemm_ws_kernel<3, 2,"),
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, gfx950 correction 2*FETCH+WRITE); null when absent"},
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
         }
         if want_cpu:
