@@ -589,7 +589,8 @@ extern "C" int aha_embed_tokens(aha_ctx* c, const int64_t* ids, int n, void* out
 static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave) {
     const int mt = ceil_div(M < 256 ? M : 256, 16);
     int kc = nt_per_wave == 1 ? (mt <= 3 ? 8 : mt <= 4 ? 4 : mt <= 8 ? 2 : 1) : (mt <= 4 ? 4 : 2);   // mirrors dispatch_mt
-    const int nc = w.KS / kc;
+    const int nc = w.KS / 8;                  // slices are placed in units of 8 k-steps (gemm_ws.hip), independent of KC
+    (void)kc;
     int S = c->split[kind];
     if (S <= 0) {
         const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);
@@ -652,7 +653,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         aha_stream* s = streams[b];
         if (!s || s->ctx != c) return fail(c, AHA_E_INVAL, "bad stream handle");
         for (int b2 = 0; b2 < b; ++b2)
-            if (streams[b2] == s) return fail(c, AHA_E_INVAL, "a stream may appear only once per step");
+            if (streams[b2] == s && !(s->policy == AHA_CACHE_STATIC && s->len > 0))
+                return fail(c, AHA_E_INVAL, "a stream may appear only once per step (except a frozen TrulyStaticCache stream, whose "
+                                            "step neither reads nor writes per-step state: its frames are independent)");
     }
     StepDesc sd;
     memset(&sd, 0, sizeof(sd));

@@ -55,8 +55,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
     int tl[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) tl[j] = min(tile0 + j, a.n_tiles - 1);
-    const int NC = a.KS / KC;                                  // chunks over the whole (padded) K
-    const int c0 = (int)(((long)blockIdx.y * NC) / a.S), c1 = (int)(((long)(blockIdx.y + 1) * NC) / a.S);
+    // split-K slice boundaries are placed in units of 8 k-steps whatever KC is, so every element is
+    // summed in the same order for every M (tile configuration): a batched step is bit-identical to
+    // the same rows stepped alone.
+    const int NC8 = a.KS / 8;
+    const int c0 = (int)(((long)blockIdx.y * NC8) / a.S) * (8 / KC), c1 = (int)(((long)(blockIdx.y + 1) * NC8) / a.S) * (8 / KC);
 
     f32x4 acc[MT][NT];
 #pragma unroll

@@ -110,6 +110,9 @@ void aha_stream_destroy(aha_stream* s);
  *                               (post-sigmoid), exp(uncertainty[b,-1])
  *   out_raw_heads fp32 [B][4] (optional) = informative logits (2), relevance logit, log-variance
  *   out_last_hidden bf16 [B][hidden] (optional) = final-norm hidden state of the last token */
+/* A stream may appear once per step; exception: a TrulyStaticCache stream after its first call is
+ * frozen (test/static_cache.py:26-36), its frames are independent, so it may be listed several
+ * times to score several frames of that stream with one pass over the weights. */
 int aha_lm_step(aha_ctx* ctx, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
                 float* out_raw_heads, void* out_last_hidden, aha_hip_stream st);
 /* all-token head outputs of the last step: fp32 [B*T][4] (LiveLlava forward()'s informative_logits /

@@ -145,7 +145,7 @@ def test_batched_streams_match_single_stream(tiny128):
         sb = rt.lm_step(both, x).cpu()
         for i in range(3):
             ss = rt.lm_step([solo[i]], x[i:i + 1]).cpu()
-            assert (ss[0] - sb[i]).abs().max().item() <= 2e-3, (step, i)
+            assert torch.equal(ss[0], sb[i]), (step, i)
             assert solo[i].get_seq_length() == both[i].get_seq_length()
     for s in solo + both:
         s.close()
@@ -353,8 +353,8 @@ def test_full_size_window_policies_equal_growing_cache_until_they_evict(bench_rt
 
 
 def test_full_size_batched_streams_and_vit_batches(bench_rt):
-    """Streams never mix: B streams in one step score like each stream alone (different GEMM tile
-    configuration, so to bf16 noise); a ViT batch encodes each frame like a batch of one (bit-exact)."""
+    """Streams never mix: B streams in one step score EXACTLY like each stream alone (any GEMM tile
+    configuration); a ViT batch encodes each frame like a batch of one (bit-exact)."""
     cfg, rt = bench_rt
     H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
     fr = make_frames(4, cfg.vision.image_size, seed=5).cuda()
@@ -369,10 +369,15 @@ def test_full_size_batched_streams_and_vit_batches(bench_rt):
         sb = _rel_unc(rt.lm_step(both, x).cpu())
         for i in range(3):
             ss = _rel_unc(rt.lm_step([solo[i]], x[i:i + 1]).cpu())
-            d = (ss[0] - sb[i]).abs()
-            # 28 layers deep, different split/tile configuration => different fp32 summation order; the
-            # head logits are bf16 (ulp 0.008-0.016 at |x| in 1..4): probabilities within 0.02,
-            # log-variance within a few logit ulps
-            assert d[:2].max().item() <= 0.02 and d[2].item() <= 0.1, (step, i, d)
+            # split-K slices are placed independently of the tile configuration, so the batched step is
+            # bit-identical to the solo step (28 layers deep, M = 108 vs 36 rows)
+            assert torch.equal(ss[0], sb[i]), (step, i)
+    # a frozen TrulyStaticCache stream may be listed several times: G frames share one weight pass
+    st = rt.open_stream("static", 2048, 0)
+    rt.lm_step([st], emb[:1, :20].contiguous())
+    seq = torch.cat([rt.lm_step([st], emb[i:i + 1]) for i in range(4)]).cpu()
+    bat = rt.lm_step([st] * 4, emb).cpu()
+    assert torch.equal(seq, bat) and st.get_seq_length() == 20
+    st.close()
     for s in solo + both:
         s.close()

@@ -82,5 +82,23 @@ int main() {
         run(n, [&](const u32x4* p) { hipLaunchKernelGGL((gridstride_k<true>), dim3(g), dim3(256), 0, 0, p, layer / 16, out); });
     }
     run("C grid-stride float4 grid=2048 x256 plain", [&](const u32x4* p) { hipLaunchKernelGGL((gridstride_k<false>), dim3(2048), dim3(256), 0, 0, p, layer / 16, out); });
+    // ---- Infinity Cache (256 MiB): re-read of a buffer that was just streamed vs a cold one
+    for (long mb : {64L, 128L, 192L}) {
+        const long bytes = mb << 20; const int waves = 1184; const int steps = (int)(bytes / 1024 / waves) / 8 * 8;
+        const long used = (long)steps * waves * 1024;
+        float cold = 0, warm = 0; const int reps = 6;
+        for (int r = 0; r < reps; ++r) {
+            // flush: stream 1 GB of other data through the caches
+            hipLaunchKernelGGL((gridstride_k<false>), dim3(2048), dim3(256), 0, 0, (const u32x4*)(buf + 2 * layer), (1L << 30) / 16, out);
+            const u32x4* p = (const u32x4*)buf;
+            float ms;
+            hipEventRecord(e0); hipLaunchKernelGGL((stream_k<8, false, false>), dim3(waves / 8), dim3(512), 0, 0, p, steps, out); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); cold += ms;
+            hipEventRecord(e0); hipLaunchKernelGGL((stream_k<8, false, true>), dim3(waves / 8), dim3(512), 0, 0, p, steps, out); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); warm += ms;
+        }
+        printf("MALL %3ld MB: cold (plain loads) %.1f us %.2f TB/s | re-read (nt loads) %.1f us %.2f TB/s\n", mb, cold / reps * 1e3,
+               used / (cold / reps * 1e-3) / 1e12, warm / reps * 1e3, used / (warm / reps * 1e-3) / 1e12);
+    }
     return 0;
 }
