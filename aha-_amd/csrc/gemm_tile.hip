@@ -46,32 +46,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // staging: each thread moves 4 chunks of A and 4 of W per k-tile: row = tid/8 + 32*i, chunk = tid%8
+    // staging: each thread moves 4 chunks of A and 4 of W per k-tile: row = tid/8 + 32*i, chunk = tid%8.
+    // The loads of k-tile kt+1 are issued before the MFMAs of tile kt and written to the other LDS
+    // buffer after them.  All loads are unconditional (indices clamped, out-of-range k chunks zeroed
+    // by a select at the store) so the compiler keeps counted waits (see gemm_ws.hip for the
+    // vmcnt(0) trap).  A second register set (two tiles in flight) was tried: it spills at
+    // 2 waves/SIMD; the 8-phase LDS-DMA template is the planned replacement.
     const int srow = tid >> 3, sch = tid & 7;
-    bf16x8 ra[4], rw[4];
-    auto gload = [&](int kt) {
-        const int k = kt * TBK + sch * 8;
-        const bool kok = k < g.K;
+    const int nk = ceil_div(g.K, TBK);
+    int aoff[4], woff[4];                                              // element offsets fit 32 bits (checked on the host)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aoff[i] = min(m0 + srow + 32 * i, g.M - 1) * g.lda;
+        woff[i] = min(n0 + srow + 32 * i, g.N - 1) * g.ldw;
+    }
+    bf16x8 raA[4], rwA[4];
+    auto gload = [&](bf16x8 (&ra)[4], bf16x8 (&rw)[4], int kt) {
+        // past the end of K: re-read the last tile / last chunk (zeroed at store time, or never stored to a live buffer)
+        const int kc = min(min(kt, nk - 1) * TBK + sch * 8, g.K - 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int am = m0 + srow + 32 * i; if (am > g.M - 1) am = g.M - 1;
-            int wn_ = n0 + srow + 32 * i; if (wn_ > g.N - 1) wn_ = g.N - 1;
-            if (kok) {
-                ra[i] = *reinterpret_cast<const bf16x8*>(g.A + (long)am * g.lda + k);
-                rw[i] = *reinterpret_cast<const bf16x8*>(g.W + (long)wn_ * g.ldw + k);
-            } else {
-                ra[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                rw[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            ra[i] = *reinterpret_cast<const bf16x8*>(g.A + aoff[i] + kc);
+            rw[i] = *reinterpret_cast<const bf16x8*>(g.W + woff[i] + kc);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](bf16x8 (&ra)[4], bf16x8 (&rw)[4], int kt, int buf) {
+        const bool kok = kt * TBK + sch * 8 < g.K;                     // the select sits at the STORE so it does not wait on the load early
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 32 * i;
             const int off = row * TBK + ((sch ^ (row & 7)) << 3);
-            *reinterpret_cast<bf16x8*>(&As[buf][off]) = ra[i];
-            *reinterpret_cast<bf16x8*>(&Ws[buf][off]) = rw[i];
+            *reinterpret_cast<bf16x8*>(&As[buf][off]) = kok ? ra[i] : z;
+            *reinterpret_cast<bf16x8*>(&Ws[buf][off]) = kok ? rw[i] : z;
         }
     };
     auto compute = [&](int buf) {
@@ -92,63 +99,66 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
         }
     };
 
-    const int nk = ceil_div(g.K, TBK);
-    gload(0);
-    lstore(0);
+    gload(raA, rwA, 0);
+    lstore(raA, rwA, 0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {                                 // issue early / write late, one tile ahead
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) gload(raA, rwA, kt + 1);                     // uniform branch around the whole batch of loads
         compute(buf);
-        if (kt + 1 < nk) lstore(buf ^ 1);
+        if (kt + 1 < nk) lstore(raA, rwA, kt + 1, buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: acc[i][j][e] <-> m = m0 + wm*64 + i*16 + r16, n = n0 + wn*64 + j*16 + q*4 + e
+    // epilogue: acc[i][j][e] <-> m = m0 + wm*64 + i*16 + r16, n = n0 + wn*64 + j*16 + q*4 + e.
+    // All side inputs (bias, residual, row-add) are fetched as 8-byte vectors and issued together
+    // BEFORE they are used: one scalar bf16 load per element made hipcc wait vmcnt(0) ~130 times per
+    // thread, which dominated the K=1024 GEMMs.  N % 4 == 0 and ld % 4 == 0 are required (checked on
+    // the host), so a 4-wide group is either fully inside or fully outside N.
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + r16;
+        const int mc = min(m, g.M - 1);
+        bf16x4 rv[4], pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+            rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
+            pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
+        }
         if (m >= g.M) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + q * 4;
             if (n >= g.N) continue;
-            float v[4];
+            bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e];
-                if (g.bias && n + e < g.N) x += bf2f(g.bias[n + e]);
-                x = rbf(x);                                   // Linear output (bf16)
+                float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));            // Linear output (bf16)
                 if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
                 else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
-                v[e] = x;
+                if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
+                if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
+                o[e] = f2bf(x);
             }
-            if (g.residual) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) v[e] = bf2f(g.residual[(long)m * g.ldr + n + e]) + v[e];
-            }
-            if (g.rowadd) {
-                const int pr = m % g.rowadd_period;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) v[e] = v[e] + bf2f(g.rowadd[(long)pr * g.ldra + n + e]);
-            }
-            if (n + 3 < g.N) {
-                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < g.N) g.C[(long)m * g.ldc + n + e] = f2bf(v[e]);
-            }
+            *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
         }
     }
 }
 
 extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
     if (g->M <= 0 || g->N <= 0) return hipSuccess;
-    if ((g->K & 7) || (g->lda & 7) || (g->ldw & 7)) return hipErrorInvalidValue;
+    if ((long)g->M * g->lda >= (1L << 31) || (long)g->N * g->ldw >= (1L << 31)) return hipErrorInvalidValue;
+    if ((g->K & 7) || (g->lda & 7) || (g->ldw & 7) || (g->N & 3) || (g->ldc & 3) || (g->residual && (g->ldr & 3)) ||
+        (g->rowadd && (g->ldra & 3)))
+        return hipErrorInvalidValue;
     const int nblk = ceil_div(g->N, TBN) * ceil_div(g->M, TBM);
     hipLaunchKernelGGL(gemm_tile_kernel, dim3(nblk), dim3(256), 0, st, *g);
     return hipGetLastError();
