@@ -121,7 +121,7 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if (d->hidden % 32 || d->inter % 32 || (d->heads * Dh) % 32) return fail(c, AHA_E_INVAL, "LM dims must be multiples of 32");
     if (d->heads % d->kv_heads) return fail(c, AHA_E_INVAL, "heads %% kv_heads != 0");
     const int vhd = d->v_hidden / d->v_heads;
-    if (vhd != 64 && vhd != 128) return fail(c, AHA_E_INVAL, "vision head_dim must be 64 or 128 (so400m's 72 not yet supported)");
+    if (vhd < 8 || vhd > 128 || (vhd & 7) || vhd * d->v_heads != d->v_hidden) return fail(c, AHA_E_INVAL, "vision head_dim must be a multiple of 8, <= 128");
     if (d->v_hidden % 8 || d->v_inter % 8 || d->v_hidden > 4096) return fail(c, AHA_E_INVAL, "vision dims must be multiples of 8, width <= 4096");
     if (d->hidden > 8192) return fail(c, AHA_E_INVAL, "hidden > 8192 unsupported");
     c->grid = d->image_size / d->patch_size;

@@ -39,6 +39,7 @@ struct AttnArgs {
     int split_len, n_splits;
     float scale;
     int layer;                                             // LM mode: cache layer index
+    int hd;                                                // real head dim (set by aha_attention)
 };
 
 struct ResidNormArgs {

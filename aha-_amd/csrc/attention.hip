@@ -46,15 +46,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
         ss = sd.s[b];
         Lk = ss.len_after;
         off = ss.causal_off;
-        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
+        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * a.hd;
         kb = ss.k_base + lo;
         vb = ss.v_base + lo;
-        ldk = D;
+        ldk = a.hd;
     } else {
         Lk = a.Lk;
         off = 1 << 30;
-        kb = a.k + b * a.kv_bs + hk * D;
-        vb = a.v + b * a.kv_bs + hk * D;
+        kb = a.k + b * a.kv_bs + hk * a.hd;
+        vb = a.v + b * a.kv_bs + hk * a.hd;
         ldk = a.ldk;
     }
     const int j0 = split * a.split_len;
@@ -72,9 +72,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
     // Q fragments (B operand): Q[row][ks*32 + 8*q4 .. +7]
     bf16x8 qf[C::KSQ];
     {
-        const bf16* qp = a.q + b * a.q_bs + (long)t * a.ldq + head * D + q4 * 8;
+        // channels >= a.hd (zero padding of a head dim that is not a template size, e.g. so400m's 72)
+        // are loaded from a clamped address and zeroed by a select: no guarded loads
+        const bf16* qp = a.q + b * a.q_bs + (long)t * a.ldq + head * a.hd;
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < C::KSQ; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32);
+        for (int ks = 0; ks < C::KSQ; ++ks) {
+            const int d0 = ks * 32 + q4 * 8;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + min(d0, a.hd - 8));
+            qf[ks] = d0 < a.hd ? v : z8;
+        }
     }
 
     f32x4 o[C::DT];
@@ -92,8 +99,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
             int j = jb + row; if (j > j1 - 1) j = j1 - 1;  // clamp: finite data, masked below
             int slot = j;
             if constexpr (LM) slot = phys_slot(ss, j);
-            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (long)slot * ldk + ch * 8);
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (long)slot * ldk + ch * 8);
+            const int dch = min(ch * 8, a.hd - 8);
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (long)slot * ldk + dch);
+            bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (long)slot * ldk + dch);
+            if (ch * 8 >= a.hd) { kv = z8; vv = z8; }
             *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * C::VST + row] = vv[e];
@@ -171,11 +181,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
     // o[dt][e] <-> d = dt*16 + 4*q4 + e of row r
     if (a.n_splits == 1) {
         const float inv = 1.0f / l_run;
-        bf16* op = a.out + b * a.o_bs + (long)t * a.ldo + head * D + 4 * q4;
+        bf16* op = a.out + b * a.o_bs + (long)t * a.ldo + head * a.hd + 4 * q4;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
             bf16x4 ov = {f2bf(o[dt][0] * inv), f2bf(o[dt][1] * inv), f2bf(o[dt][2] * inv), f2bf(o[dt][3] * inv)};
-            *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+            if (dt * 16 + 4 * q4 < a.hd) *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
         }
     } else {
         const int Rpad = RT * 16;
@@ -208,7 +218,7 @@ __global__ void attn_combine_kernel(AttnArgs a, StepDesc sd) {
         acc += w * a.part_o[prow * D + d];
     }
     const int g = r / a.T, t = r % a.T;
-    a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d] = f2bf(acc / L);
+    if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(acc / L);
 }
 
 template <int D>
@@ -228,9 +238,13 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipS
 }
 
 // sd == nullptr: dense (ViT) mode, requires n_splits == 1.
-extern "C" hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
-    if (!sd && a->n_splits != 1) return hipErrorInvalidValue;
-    if (head_dim == 64) return launch_attn<64>(*a, sd, B, st);
-    if (head_dim == 128) return launch_attn<128>(*a, sd, B, st);
-    return hipErrorInvalidValue;
+// head_dim: any multiple of 8 up to 128; it runs the 64- or 128-wide template with the surplus
+// channels zero-padded on chip (so400m: 72 -> 128).
+extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
+    if (!sd && a_->n_splits != 1) return hipErrorInvalidValue;
+    if (head_dim < 8 || head_dim > 128 || (head_dim & 7)) return hipErrorInvalidValue;
+    AttnArgs a = *a_;
+    a.hd = head_dim;
+    if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
+    return launch_attn<128>(a, sd, B, st);
 }

@@ -381,3 +381,27 @@ def test_full_size_batched_streams_and_vit_batches(bench_rt):
     st.close()
     for s in solo + both:
         s.close()
+
+
+def test_reference_faithful_vision_shapes_head_dim_72():
+    """so400m/14@384 geometry of the reference (arguments_live.py:22-24): width 1152,
+    16 heads x 72, MLP 4304, 729 patches, bilinear 27 -> 7 pooling (49 tokens/frame), at 2 layers."""
+    from aha_amd.config import LiveConfig, LMConfig, VisionConfig
+    from oracle.vision_tower import OracleVision, preprocess
+    cfg = LiveConfig(vision=VisionConfig(image_size=384, patch_size=14, hidden_size=1152, num_hidden_layers=2,
+                                         num_attention_heads=16, intermediate_size=4304),
+                     lm=LMConfig(hidden_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                                 head_dim=64, intermediate_size=512, vocab_size=512), name="ref2l")
+    assert cfg.frame_num_tokens == 49 and cfg.vision.head_dim == 72 and cfg.vision.num_patches == 729
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=2, max_positions=1024)
+    fr = make_frames(2, 384, seed=2)
+    ov = OracleVision(cfg, w, torch.bfloat16)
+    want_t = ov.tower(preprocess(fr, torch.bfloat16)).float()
+    want_e = ov.visual_embed(fr).float()
+    got_e = rt.visual_embed(fr.cuda()).float().cpu()
+    got_t = rt.tower_output(2).float().cpu().view_as(want_t)
+    assert (got_t - want_t).abs().max().item() <= 0.03 * max(1.0, want_t.abs().max().item())
+    assert (got_e - want_e).abs().max().item() <= 0.03 * max(1.0, want_e.abs().max().item())
+    assert got_e.shape == (2 * 49, 256)
+    rt.close()
