@@ -12,8 +12,6 @@
 #include "aha_kernels.h"
 
 
-#define TBM 128
-#define TBN 128
 #define TBK 64
 
 static __device__ __forceinline__ float gelu_tanh_f(float x) {
@@ -24,7 +22,11 @@ static __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 static __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
+// WT = 16x16 MFMA tiles per wave per dimension: WT = 4 -> 128x128 block tile (throughput shapes),
+// WT = 2 -> 64x64 block tile (M <= ~1k rows: single-frame latency; 4x the workgroups).
+template <int WT>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
+    constexpr int TBM = 32 * WT, TBN = 32 * WT;
     __shared__ __attribute__((aligned(16))) bf16 As[2][TBM * TBK];
     __shared__ __attribute__((aligned(16))) bf16 Ws[2][TBN * TBK];
 
@@ -40,11 +42,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
     const int bm = bid / tiles_n, bn = bid % tiles_n;
     const int m0 = bm * TBM, n0 = bn * TBN;
 
-    f32x4 acc[4][4];
+    f32x4 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging: each thread moves 4 chunks of A and 4 of W per k-tile: row = tid/8 + 32*i, chunk = tid%8.
     // The loads of k-tile kt+1 are issued before the MFMAs of tile kt and written to the other LDS
@@ -54,27 +56,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
     // 2 waves/SIMD; the 8-phase LDS-DMA template is the planned replacement.
     const int srow = tid >> 3, sch = tid & 7;
     const int nk = ceil_div(g.K, TBK);
-    int aoff[4], woff[4];                                              // element offsets fit 32 bits (checked on the host)
+    int aoff[WT], woff[WT];                                              // element offsets fit 32 bits (checked on the host)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < WT; ++i) {
         aoff[i] = min(m0 + srow + 32 * i, g.M - 1) * g.lda;
         woff[i] = min(n0 + srow + 32 * i, g.N - 1) * g.ldw;
     }
-    bf16x8 raA[4], rwA[4];
-    auto gload = [&](bf16x8 (&ra)[4], bf16x8 (&rw)[4], int kt) {
+    bf16x8 raA[WT], rwA[WT];
+    auto gload = [&](bf16x8 (&ra)[WT], bf16x8 (&rw)[WT], int kt) {
         // past the end of K: re-read the last tile / last chunk (zeroed at store time, or never stored to a live buffer)
         const int kc = min(min(kt, nk - 1) * TBK + sch * 8, g.K - 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
             ra[i] = *reinterpret_cast<const bf16x8*>(g.A + aoff[i] + kc);
             rw[i] = *reinterpret_cast<const bf16x8*>(g.W + woff[i] + kc);
         }
     };
-    auto lstore = [&](bf16x8 (&ra)[4], bf16x8 (&rw)[4], int kt, int buf) {
+    auto lstore = [&](bf16x8 (&ra)[WT], bf16x8 (&rw)[WT], int kt, int buf) {
         const bool kok = kt * TBK + sch * 8 < g.K;                     // the select sits at the STORE so it does not wait on the load early
         const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < WT; ++i) {
             const int row = srow + 32 * i;
             const int off = row * TBK + ((sch ^ (row & 7)) << 3);
             *reinterpret_cast<bf16x8*>(&As[buf][off]) = kok ? ra[i] : z;
@@ -84,18 +86,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
     auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < TBK / 32; ++ks) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[WT], wf[WT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + r16;
+            for (int i = 0; i < WT; ++i) {
+                const int row = wm * (16 * WT) + i * 16 + r16;
                 af[i] = *reinterpret_cast<const bf16x8*>(&As[buf][row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
-                const int wrow = wn * 64 + i * 16 + r16;
+                const int wrow = wn * (16 * WT) + i * 16 + r16;
                 wf[i] = *reinterpret_cast<const bf16x8*>(&Ws[buf][wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
     };
 
@@ -116,27 +118,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
     // thread, which dominated the K=1024 GEMMs.  N % 4 == 0 and ld % 4 == 0 are required (checked on
     // the host), so a 4-wide group is either fully inside or fully outside N.
     const bf16x4 z4 = {0, 0, 0, 0};
-    bf16x4 bv[4];
+    bf16x4 bv[WT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+    for (int j = 0; j < WT; ++j) {
+        const int n = min(n0 + wn * (16 * WT) + j * 16 + q * 4, g.N - 4);
         bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r16;
+    for (int i = 0; i < WT; ++i) {
+        const int m = m0 + wm * (16 * WT) + i * 16 + r16;
         const int mc = min(m, g.M - 1);
-        bf16x4 rv[4], pv[4];
+        bf16x4 rv[WT], pv[WT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+        for (int j = 0; j < WT; ++j) {
+            const int n = min(n0 + wn * (16 * WT) + j * 16 + q * 4, g.N - 4);
             rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
             pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
         }
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + q * 4;
+        for (int j = 0; j < WT; ++j) {
+            const int n = n0 + wn * (16 * WT) + j * 16 + q * 4;
             if (n >= g.N) continue;
             bf16x4 o;
 #pragma unroll
@@ -159,7 +161,12 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
     if ((g->K & 7) || (g->lda & 7) || (g->ldw & 7) || (g->N & 3) || (g->ldc & 3) || (g->residual && (g->ldr & 3)) ||
         (g->rowadd && (g->ldra & 3)))
         return hipErrorInvalidValue;
-    const int nblk = ceil_div(g->N, TBN) * ceil_div(g->M, TBM);
-    hipLaunchKernelGGL(gemm_tile_kernel, dim3(nblk), dim3(256), 0, st, *g);
+    const int nblk128 = ceil_div(g->N, 128) * ceil_div(g->M, 128);
+    if (nblk128 >= 384) {            // enough 128x128 tiles to fill 256 CUs at 2 workgroups each
+        hipLaunchKernelGGL((gemm_tile_kernel<4>), dim3(nblk128), dim3(256), 0, st, *g);
+    } else {
+        const int nblk64 = ceil_div(g->N, 64) * ceil_div(g->M, 64);
+        hipLaunchKernelGGL((gemm_tile_kernel<2>), dim3(nblk64), dim3(256), 0, st, *g);
+    }
     return hipGetLastError();
 }
