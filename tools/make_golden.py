@@ -124,8 +124,39 @@ def gen_siglip():
     print("siglip_tiny.npz")
 
 
+def postproc_inputs(seed=0, n_videos=4):
+    """Seeded synthetic TVSum-shaped data: GT = mean of 20 annotators' 1..5 scores / 5 (ties on purpose,
+    tvsum_utils.py:95-122), predictions = noisy monotone function of GT."""
+    rng = np.random.RandomState(seed)
+    gt, pred = {}, {}
+    for v in range(n_videos):
+        n = int(rng.randint(80, 200))
+        base = np.clip(np.cumsum(rng.randn(n)) * 0.3 + 3, 1, 5)
+        ann = np.clip(np.rint(base[None] + rng.randn(20, n) * 0.7), 1, 5)
+        g = ann.mean(0) / 5.0
+        gt[f"v{v}"] = g
+        pred[f"v{v}"] = np.round(0.6 * g + 0.25 * rng.rand(n), 3)          # rounded: ties in predictions too
+    return gt, pred
+
+
+def gen_postproc():
+    import json
+    sys.path.insert(0, "/root/reference")
+    from test.tvsum.tvsum_utils import evaluate_tvsum, evaluate_f1
+    from test.hisum.hisum_eval import hisum_evaluate_scores
+    gt, pred = postproc_inputs()
+    m50, m15, top5, spe, ken = evaluate_tvsum(gt, pred)
+    h = hisum_evaluate_scores(gt, pred, spearman_kendall=True, print_logs=False)
+    out = {"tvsum": {"mAP50": float(m50), "mAP15": float(m15), "top5": float(top5), "spearman": float(spe),
+                     "kendall": float(ken), "f1_15": float(evaluate_f1(gt, pred))},
+           "hisum": {k: float(v) for k, v in h.items()}}
+    json.dump(out, open(os.path.join(OUT, "postproc.json"), "w"), indent=1)
+    print("postproc.json", out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_postproc()
     gen_cache()
     gen_qwen2()
     gen_siglip()
