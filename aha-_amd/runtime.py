@@ -169,13 +169,16 @@ class Runtime:
         self._chk(self.lib.aha_ctx_set_rerotation_table(self.ctx, W, k, T, rc.data_ptr(), rs.data_ptr(), _cur_stream()))
 
     # -- the hot path ------------------------------------------------------------------------------
-    def visual_embed(self, frames_u8: torch.Tensor) -> torch.Tensor:
+    def visual_embed(self, frames_u8: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """uint8 [N,3,S,S] on device -> bf16 [N*Tf, H] (LiveMixin.visual_embed, modeling_live.py:31-37,
-        with image_processor.preprocess fused in)."""
+        with image_processor.preprocess fused in).  Runs on the CURRENT torch stream; pass a
+        preallocated `out` when encoding on a side stream (overlap with LM steps)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4
         frames_u8 = frames_u8.contiguous()
         n = frames_u8.shape[0]
-        out = torch.empty((n * self.frame_num_tokens, self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        if out is None:
+            out = torch.empty((n * self.frame_num_tokens, self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        assert out.is_contiguous() and out.numel() == n * self.frame_num_tokens * self.hidden_size
         step = self.desc.max_vit_frames
         for i in range(0, n, step):
             m = min(step, n - i)
