@@ -64,6 +64,8 @@ struct aha_ctx {
     int wpb[GK_COUNT] = {4, 4, 8, 8};        // waves per workgroup per GEMM kind (measured: tools/tune_lm.py)
     int attn_split_len = 0;
     int time_gemm = 0;
+    int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
+                                         // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
     // accounting of the last step
     double last_weight_bytes = 0, last_kv_bytes = 0, last_flops = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GK_COUNT];
@@ -185,6 +187,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "wpb_down") c->wpb[GK_DOWN] = value;
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
+    else if (k == "fuse_static") c->fuse_static = value;
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
     return 0;
 }
@@ -708,22 +711,34 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
     if (n_splits < 1) n_splits = 1;
 
+    bool frozen_all = c->fuse_static != 0;
+    for (int b = 0; b < B; ++b) frozen_all = frozen_all && sd.s[b].write_base < 0;
     int rc;
     for (int l = 0; l < d.layers; ++l) {
         const LayerW& w = c->L[l];
-        // QKV projection -> split-K slabs
+        // QKV projection -> split-K slabs.  When every stream of the step is a frozen TrulyStaticCache
+        // (nothing is stored, the new tokens' K/V are never read: test/static_cache.py:33-36) only the
+        // q tiles are projected (they come first in the packed q|k|v weight) and the attention kernel
+        // builds Q from the slabs itself: no K/V GEMM columns, no qkv_finish launch.
+        PackedW wq = w.qkv;
+        if (frozen_all) { wq.n_tiles = QD / 16; wq.N = QD; }
         const int nq_ld = w.qkv.n_tiles * 16;
-        const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);
-        if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, w.qkv, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
-        QkvFinishArgs qa;
-        memset(&qa, 0, sizeof(qa));
-        qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
-        qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
-        qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
-        HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
-        // attention over the stream caches
+        const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);      // same split as the full projection: bit-identical q
+        if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
         AttnArgs a;
         memset(&a, 0, sizeof(a));
+        if (!frozen_all) {
+            QkvFinishArgs qa;
+            memset(&qa, 0, sizeof(qa));
+            qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+            qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+            qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+            HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
+        } else {
+            a.q_partial = c->partial; a.q_S = Sq; a.q_slab_stride = (long)M * nq_ld; a.q_ldp = nq_ld; a.q_bias = w.qkv_bias;
+            a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.n_pos = c->n_pos;
+        }
+        // attention over the stream caches
         a.q = c->q_rot; a.q_bs = (long)T * QD; a.ldq = QD;
         a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
         a.part_o = c->part_o; a.part_ml = c->part_ml;

@@ -40,6 +40,9 @@ struct AttnArgs {
     float scale;
     int layer;                                             // LM mode: cache layer index
     int hd;                                                // real head dim (set by aha_attention)
+    // LM, frozen-static steps only: Q from the QKV GEMM's split-K slabs (null -> read a.q)
+    const float* q_partial; int q_S; long q_slab_stride; int q_ldp;
+    const bf16* q_bias; const bf16* rope_cos; const bf16* rope_sin; int n_pos;
 };
 
 struct ResidNormArgs {

@@ -71,7 +71,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
 
     // Q fragments (B operand): Q[row][ks*32 + 8*q4 .. +7]
     bf16x8 qf[C::KSQ];
-    {
+    if (LM && a.q_partial) {
+        // Frozen-static steps: build Q straight from the QKV GEMM's split-K slabs - reduce + bias ->
+        // bf16, RoPE (modeling_qwen2.py:107-131) with the pair (d, d + D/2) held by the same lane in
+        // qf[ks] / qf[ks + KSQ/2] - so no qkv_finish launch and no q_rot round trip.  Same rounding
+        // points as qkv_finish_kernel (bit-identical Q).
+        const int m = b * a.T + t;
+        const int pos = min(ss.pos_base + t, a.n_pos - 1);
+        float xq[C::KSQ][8];
+#pragma unroll
+        for (int ks = 0; ks < C::KSQ; ++ks) {
+            const int col = head * D + ks * 32 + q4 * 8;
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            const float* p = a.q_partial + (long)m * a.q_ldp + col;
+            for (int s0 = 0; s0 < a.q_S; s0 += 8) {
+                f32x4 t0[8], t1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j < a.q_S) {
+                        t0[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.q_slab_stride);
+                        t1[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.q_slab_stride + 4);
+                    }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j < a.q_S) { a0 += t0[j]; a1 += t1[j]; }
+            }
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(a.q_bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xq[ks][e] = rbf(a0[e] + bf2f(bv[e]));
+                xq[ks][4 + e] = rbf(a1[e] + bf2f(bv[4 + e]));
+            }
+        }
+        constexpr int HK = C::KSQ / 2;
+#pragma unroll
+        for (int ks = 0; ks < HK; ++ks) {
+            const int d = ks * 32 + q4 * 8;
+            const bf16x8 c1 = *reinterpret_cast<const bf16x8*>(a.rope_cos + (long)pos * D + d);
+            const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(a.rope_sin + (long)pos * D + d);
+            const bf16x8 c2 = *reinterpret_cast<const bf16x8*>(a.rope_cos + (long)pos * D + d + D / 2);
+            const bf16x8 s2 = *reinterpret_cast<const bf16x8*>(a.rope_sin + (long)pos * D + d + D / 2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x1 = xq[ks][e], x2 = xq[ks + HK][e];
+                qf[ks][e] = f2bf(rbf(x1 * bf2f(c1[e])) + rbf(-x2 * bf2f(s1[e])));
+                qf[ks + HK][e] = f2bf(rbf(x2 * bf2f(c2[e])) + rbf(x1 * bf2f(s2[e])));
+            }
+        }
+    } else {
         // channels >= a.hd (zero padding of a head dim that is not a template size, e.g. so400m's 72)
         // are loaded from a clamped address and zeroed by a select: no guarded loads
         const bf16* qp = a.q + b * a.q_bs + (long)t * a.ldq + head * a.hd;

@@ -405,3 +405,22 @@ def test_reference_faithful_vision_shapes_head_dim_72():
     assert (got_e - want_e).abs().max().item() <= 0.03 * max(1.0, want_e.abs().max().item())
     assert got_e.shape == (2 * 49, 256)
     rt.close()
+
+
+def test_frozen_static_fusion_is_bit_identical(tiny128):
+    """Opt-in `fuse_static`: frozen TrulyStaticCache steps skip the K/V projection and build Q inside the
+    attention kernel from the split-K slabs - must not change a single bit."""
+    cfg, w, rt = tiny128
+    g = torch.Generator().manual_seed(12)
+    prefix = (torch.randn(1, 11, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16().cuda()
+    xs = (torch.randn(5, 9, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16().cuda()
+    out = {}
+    for fuse in (0, 1):
+        rt.set_tuning("fuse_static", fuse)
+        st = rt.open_stream("static", 64, 0)
+        rt.lm_step([st], prefix)
+        out[fuse] = torch.cat([rt.lm_step([st], xs[i:i + 1], want_raw=True)[1] for i in range(5)]).cpu()
+        out[(fuse, "b")] = rt.lm_step([st] * 5, xs, want_raw=True)[1].cpu()
+        st.close()
+    rt.set_tuning("fuse_static", 0)
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[(1, "b")]) and torch.equal(out[0], out[(0, "b")])
