@@ -590,10 +590,8 @@ extern "C" int aha_embed_tokens(aha_ctx* c, const int64_t* ids, int n, void* out
 // LM step
 // --------------------------------------------------------------------------------------------
 static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave) {
-    const int mt = ceil_div(M < 256 ? M : 256, 16);
-    int kc = nt_per_wave == 1 ? (mt <= 3 ? 8 : mt <= 4 ? 4 : mt <= 8 ? 2 : 1) : (mt <= 4 ? 4 : 2);   // mirrors dispatch_mt
+    (void)M;                                  // S must NOT depend on M: a batched step stays bit-identical to solo steps
     const int nc = w.KS / 8;                  // slices are placed in units of 8 k-steps (gemm_ws.hip), independent of KC
-    (void)kc;
     int S = c->split[kind];
     if (S <= 0) {
         const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);

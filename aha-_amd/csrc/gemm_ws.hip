@@ -267,41 +267,47 @@ static thread_local int g_wpb = 4;      // waves per workgroup for the next disp
 
 template <int MT, int NT, int KC, int EPI>
 static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
-    if constexpr (MT <= 4) {            // 2- and 8-wave variants exist for the single-stream shapes
+    if constexpr (MT <= 4) {            // single-stream shapes: 2-, 4- and 8-wave workgroups (tuning knob)
         if (g_wpb == 2) return launch_ws_w<MT, NT, KC, EPI, 2>(a, st);
         if (g_wpb == 8) return launch_ws_w<MT, NT, KC, EPI, 8>(a, st);
+        return launch_ws_w<MT, NT, KC, EPI, 4>(a, st);
+    } else {                            // batched shapes: always 8-wave workgroups (X image shared by 8 waves)
+        return launch_ws_w<MT, NT, KC, EPI, 8>(a, st);
     }
-    return launch_ws_w<MT, NT, KC, EPI, 4>(a, st);
 }
 
 template <int NT, int EPI>
 static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
-    // KC (k-steps of 32 per pipeline chunk) shrinks as the accumulator tile grows so that three
-    // weight register sets + accumulators stay under 256 VGPRs (2 waves/SIMD, no spills).
-    // aha_api.hip:pick_split mirrors this table.
+    // KC (k-steps of 32 per pipeline chunk, one barrier per chunk) is the largest of {8,4,2,1} for which
+    // three weight register sets + accumulators + X staging stay under 256 VGPRs without spills and the
+    // two X buffers fit the 160 KB LDS (checked with -Rpass-analysis=kernel-resource-usage).
     const int mt = ceil_div(a.M, 16);
     if constexpr (NT == 1) {
         if (mt <= 1) return launch_ws<1, 1, 8, EPI>(a, st);
         if (mt <= 2) return launch_ws<2, 1, 8, EPI>(a, st);
         if (mt <= 3) return launch_ws<3, 1, 8, EPI>(a, st);
         if (mt <= 4) return launch_ws<4, 1, 4, EPI>(a, st);
-        if (mt <= 6) return launch_ws<6, 1, 2, EPI>(a, st);
-        if (mt <= 8) return launch_ws<8, 1, 2, EPI>(a, st);
-        if (mt <= 12) return launch_ws<12, 1, 1, EPI>(a, st);
-        if (mt <= 16) return launch_ws<16, 1, 1, EPI>(a, st);
+        if (mt <= 6) return launch_ws<6, 1, 4, EPI>(a, st);
+        if (mt <= 8) return launch_ws<8, 1, 4, EPI>(a, st);
+        if (mt <= 12) return launch_ws<12, 1, 4, EPI>(a, st);
+        if (mt <= 16) return launch_ws<16, 1, 2, EPI>(a, st);
+        if (mt <= 20) return launch_ws<20, 1, 2, EPI>(a, st);
+        if (mt <= 26) return launch_ws<26, 1, 1, EPI>(a, st);
     } else {
         if (mt <= 1) return launch_ws<1, 2, 4, EPI>(a, st);
         if (mt <= 2) return launch_ws<2, 2, 4, EPI>(a, st);
         if (mt <= 3) return launch_ws<3, 2, 4, EPI>(a, st);
         if (mt <= 4) return launch_ws<4, 2, 4, EPI>(a, st);
-        if (mt <= 6) return launch_ws<6, 2, 2, EPI>(a, st);
+        if (mt <= 6) return launch_ws<6, 2, 4, EPI>(a, st);
         if (mt <= 8) return launch_ws<8, 2, 2, EPI>(a, st);
+        if (mt <= 12) return launch_ws<12, 2, 1, EPI>(a, st);
+        if (mt <= 16) return launch_ws<16, 2, 1, EPI>(a, st);
     }
     return hipErrorInvalidValue;               // caller chunks M
 }
 
 // Largest M each epilogue supports in one launch (the host loops over row chunks beyond it).
-extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 128 : 256; }
+extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 256 : 416; }
 
 extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
     g_wpb = (wpb == 2 || wpb == 8) ? wpb : 4;
