@@ -254,15 +254,39 @@ class LiveInferForBenchmark:
         return response
 
     # ---- test/inference.py:283-335 ---------------------------------------------------------------
+    def _encode_frames_static_batched(self, frames_per_step: int):
+        """TrulyStaticCache only: once the cache is frozen a frame's scores do not depend on any other
+        frame (test/static_cache.py:26-36), so `frames_per_step` queued frames are scored with ONE pass over
+        the weights (the frozen stream is listed once per frame).  Bit-identical to scoring them one by
+        one; used by inference() only while no query / prompt prefix has to be interleaved."""
+        g = min(frames_per_step, len(self.frame_embeds_queue))
+        embeds = torch.stack([self.frame_embeds_queue.popleft()[1] for _ in range(g)]).view(g, -1, self.hidden_size)
+        scores = self.rt.lm_step([self.past_key_values] * g, embeds).tolist()
+        self.frame_idx += g
+        self.num_frames_no_reply += g
+        self.last_role = "stream"
+        self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        return scores
+
     @torch.no_grad()
-    def inference(self, verbose=False, total=None):
+    def inference(self, verbose=False, total=None, frames_per_step: int = 1):
         model_response_list = [{"time": q[0], "content": q[1], "role": "user"} for q in self.query_queue]
-        while self.frame_embeds_queue:
+        pending = collections.deque()        # scores already computed by a static batched step
+        while self.frame_embeds_queue or pending:
             # 1. check if a user query is at current time
             if self.query_queue and self.video_time >= self.query_queue[0][0]:
                 self._encode_query()
             # 2. input a frame, and update the scores list
-            video_scores, uncertainty_score = self._encode_frame()
+            can_batch = (frames_per_step > 1 and self.alt_cache == "static" and not self.sink_cache and self.init_vision_time
+                         and self.last_role == "stream" and self.past_key_values.get_seq_length() > 0
+                         and not (self.query_queue and self.query_queue[0][0] <= self.video_time + (frames_per_step - 1) / self.frame_fps))
+            if not pending and can_batch and len(self.frame_embeds_queue) > 1:
+                pending.extend(self._encode_frames_static_batched(frames_per_step))
+            if pending:
+                s = pending.popleft()
+                video_scores, uncertainty_score = {"informative_score": s[0], "relevance_score": s[1]}, s[2]
+            else:
+                video_scores, uncertainty_score = self._encode_frame()
             self.debug_data_list.append(dict(time=self.video_time, **video_scores, uncertainty_score=uncertainty_score))
             # 3. check the scores, if need to generate a response
             need_response = False
@@ -277,6 +301,8 @@ class LiveInferForBenchmark:
             if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
                 need_response = True
             # 4. record the responses
+            if need_response and pending:
+                raise RuntimeError("a response was triggered inside a static batched step: use frames_per_step=1 with response thresholds")
             if need_response:
                 response = self._generate_response()
                 model_response_list.append({"time": self.video_time, "content": response, "role": "assistant"})

@@ -40,6 +40,7 @@ def parse():
     p.add_argument("--window", type=int, default=2048)
     p.add_argument("--sink", type=int, default=32)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     return p.parse_args()
@@ -152,7 +153,7 @@ def main():
     # the tower of batch k+1 runs on a second HIP stream while the LM scores batch k (double-buffered
     # embeddings, events both ways).  Every batch's encode and all of its LM steps are inside the
     # timed region; --no-overlap serialises them on one stream.
-    main_stream = torch.cuda.current_stream()
+    main_stream = torch.cuda.Stream(priority=-1) if a.lm_priority else torch.cuda.current_stream()   # LM chain: short kernels
     vit_stream = torch.cuda.Stream() if not a.no_overlap else main_stream
     emb_buf = [torch.empty((B * F * tf, H), dtype=torch.bfloat16, device=dev) for _ in range(2)]
     emb_ready = [torch.cuda.Event() for _ in range(2)]
@@ -167,6 +168,10 @@ def main():
             emb_ready[k & 1].record(vit_stream)
 
     def run(n_steps):
+        with torch.cuda.stream(main_stream):
+            _run(n_steps)
+
+    def _run(n_steps):
         encode(0)
         for k in range(n_steps):
             if k + 1 < n_steps:

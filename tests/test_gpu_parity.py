@@ -424,3 +424,34 @@ def test_frozen_static_fusion_is_bit_identical(tiny128):
         st.close()
     rt.set_tuning("fuse_static", 0)
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[(1, "b")]) and torch.equal(out[0], out[(0, "b")])
+
+
+def test_driver_static_batched_equals_sequential(tiny):
+    from aha_amd.arguments import LiveTestArguments
+    from aha_amd.live_infer import LiveInferForBenchmark
+    cfg, w, rt = tiny
+    frames = make_frames(11, cfg.vision.image_size, seed=9)
+    out = []
+    for fps_ in (1, 4):
+        drv = LiveInferForBenchmark(LiveTestArguments(frame_fps=1, stream_end_prob_threshold=9.0), alt_cache="static", runtime=rt)
+        drv.input_video_stream(frames)
+        drv.input_query_stream([{"role": "user", "content": "what now", "time": 0}])
+        drv.inference(frames_per_step=fps_)
+        out.append(drv.debug_data_list)
+    assert out[0] == out[1] and len(out[0]) == 11
+
+
+def test_long_sink_stream_bookkeeping_and_reproducibility(bench_rt):
+    """configs[2] in small: 150 frames through SinkCache(W=2048, sink=32) on the full model, twice."""
+    cfg, rt = bench_rt
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    fr = make_frames(8, cfg.vision.image_size, seed=11).cuda()
+    emb = rt.visual_embed(fr).view(8, tf, H)
+    runs = []
+    for rep in range(2):
+        st = rt.open_stream("default_sink", 2048, 32)
+        sc = torch.cat([rt.lm_step([st], emb[i % 8:i % 8 + 1]) for i in range(150)]).cpu()
+        assert torch.isfinite(sc).all() and st.get_seq_length() == 2048 and st.seen_tokens == 150 * tf
+        runs.append(sc)
+        st.close()
+    assert torch.equal(runs[0], runs[1])
