@@ -47,6 +47,7 @@ struct aha_ctx {
     bf16 *patch_w = nullptr, *patch_b = nullptr, *pos_emb = nullptr;
     std::vector<VLayerW> V;
     bf16 *p0w = nullptr, *p0b = nullptr, *p2w = nullptr, *p2b = nullptr;
+    bf16 *post_ln_w = nullptr, *post_ln_b = nullptr;      // optional: only the vision_live.py contract uses the tower's post_layernorm
     // tables
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
@@ -328,6 +329,10 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
         if ((rc = copy_vec(c, m, p + "mlp.fc2.weight", (int64_t)Dv * d.v_inter, &w.w2, st))) return rc;
         if ((rc = copy_vec(c, m, p + "mlp.fc2.bias", Dv, &w.b2, st))) return rc;
     }
+    if (m.count("vision.post_layernorm.weight") && m.count("vision.post_layernorm.bias")) {
+        if ((rc = copy_vec(c, m, "vision.post_layernorm.weight", Dv, &c->post_ln_w, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.post_layernorm.bias", Dv, &c->post_ln_b, st))) return rc;
+    }
     if ((rc = copy_vec(c, m, "mm_projector.0.weight", (int64_t)H * Dv, &c->p0w, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.0.bias", H, &c->p0b, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.2.weight", (int64_t)H * H, &c->p2w, st))) return rc;
@@ -538,14 +543,9 @@ static hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ld
     return aha_gemm_tile(&g, st);
 }
 
-extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* out_embeds, aha_hip_stream st_) {
-    if (!c || !frames || !out_embeds) return AHA_E_INVAL;
-    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
-    if (n <= 0) return 0;
-    if (n > c->d.max_vit_frames) return fail(c, AHA_E_RANGE, "n_frames > max_vit_frames");
-    hipStream_t st = (hipStream_t)st_;
+static int vit_tower(aha_ctx* c, const uint8_t* frames, int n, hipStream_t st) {
     const aha_model_desc& d = c->d;
-    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden, vhd = Dv / d.v_heads;
+    const int Dv = d.v_hidden, rows = n * c->Np, vhd = Dv / d.v_heads;
     HIPCHK(c, aha_im2col_norm(frames, n, d.image_size, d.patch_size, c->Kp, c->v_a0, st));
     HIPCHK(c, tile_gemm(c->v_a0, c->Kp, rows, c->patch_w, c->Kp, Dv, c->Kp, c->v_x, Dv, c->patch_b, ACT_NONE, nullptr, 0,
                         c->pos_emb, c->Np, Dv, st));
@@ -567,9 +567,46 @@ extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* ou
         HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, d.v_inter, w.b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
         HIPCHK(c, tile_gemm(c->v_f, d.v_inter, rows, w.w2, d.v_inter, Dv, d.v_inter, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
     }
+    return 0;
+}
+
+static int vit_check(aha_ctx* c, const void* frames, const void* out, int n) {
+    if (!c || !frames || !out) return AHA_E_INVAL;
+    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
+    if (n > c->d.max_vit_frames) return fail(c, AHA_E_RANGE, "n_frames > max_vit_frames");
+    return 0;
+}
+
+extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* out_embeds, aha_hip_stream st_) {
+    int rc = vit_check(c, frames, out_embeds, n);
+    if (rc || n <= 0) return rc;
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden;
+    if ((rc = vit_tower(c, frames, n, st))) return rc;
     HIPCHK(c, tile_gemm(c->v_x, Dv, rows, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, rows, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, st));
+    return 0;
+}
+
+// The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode, frame_token_cls=False):
+// tower -> post_layernorm (last_hidden_state) -> adaptive_avg_pool2d to pooled x pooled -> connector.
+// Pooling happens BEFORE the projector, so the projector runs on pooled^2 rows per frame.
+extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, int n, int pooled, void* out_embeds,
+                                           aha_hip_stream st_) {
+    int rc = vit_check(c, frames, out_embeds, n);
+    if (rc || n <= 0) return rc;
+    if (!c->post_ln_w) return fail(c, AHA_E_NOENT, "vision.post_layernorm.{weight,bias} were not loaded");
+    if (pooled <= 0 || pooled > c->grid) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid");
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden, prow = n * pooled * pooled;
+    if ((rc = vit_tower(c, frames, n, st))) return rc;
+    HIPCHK(c, aha_layernorm(c->v_x, Dv, c->post_ln_w, c->post_ln_b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+    HIPCHK(c, aha_pool(c->v_h, c->v_attn, n, c->grid, pooled, Dv, 0, 3, st));
+    HIPCHK(c, tile_gemm(c->v_attn, Dv, prow, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
+    HIPCHK(c, tile_gemm(c->v_p1, H, prow, c->p2w, H, H, H, (bf16*)out_embeds, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
     return 0;
 }
 

@@ -395,6 +395,21 @@ __global__ void pool_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             acc[e] = hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
+    } else if (mode == 3) {
+        // adaptive_avg_pool2d g -> go (models/vision_live.py:18-25): window [floor(o*g/go), ceil((o+1)*g/go))
+        const int y0 = (oy * g) / go, y1 = ((oy + 1) * g + go - 1) / go;
+        const int x0 = (ox * g) / go, x1 = ((ox + 1) * g + go - 1) / go;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + ((long)y * g + x) * H);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += bf2f(vv[e]);
+            }
+        const float cnt = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] / cnt;
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = (mode == 1) ? 0.f : -INFINITY;

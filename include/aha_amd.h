@@ -84,6 +84,12 @@ const char* aha_last_error(aha_ctx* ctx);
  * post_projector_pooling (video_head_live_llava_qwen.py:107-136) ----------------------------- */
 /* frames_u8: [n,3,S,S] uint8 RGB; out_embeds: bf16 [n*Tf][hidden] */
 int aha_vit_encode(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* out_embeds, aha_hip_stream st);
+/* The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode, frame_token_cls=False) followed
+ * by LiveMixin's connector (models/modeling_live.py:31-37): tower -> post_layernorm (last_hidden_state) ->
+ * adaptive_avg_pool2d to pooled x pooled (frame_token_pooled, models/arguments_live.py:21) -> mm_projector.
+ * Needs "vision.post_layernorm.{weight,bias}".  out_embeds: bf16 [n*pooled*pooled][hidden] */
+int aha_vit_encode_pooled_first(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, int pooled, void* out_embeds,
+                                aha_hip_stream st);
 /* parity-test tap: copy the tower output of the last encode, bf16 [n_frames*Np][v_hidden] */
 int aha_vit_last_tower_output(aha_ctx* ctx, int n_frames, void* out, aha_hip_stream st);
 

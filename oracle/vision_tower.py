@@ -111,3 +111,21 @@ class OracleVision:
         x = self.connector(x)
         x = self.post_projector_pooling(x)
         return x.reshape(-1, x.shape[-1])
+
+
+def vision_live_encode(ov: "OracleVision", frames_u8: torch.Tensor, post_ln_w: torch.Tensor, post_ln_b: torch.Tensor,
+                       frame_token_pooled=(7, 7)) -> torch.Tensor:
+    """models/vision_live.py:11-31 (_siglip_vision_encode with frame_token_cls=False) then LiveMixin.visual_embed's
+    connector (models/modeling_live.py:31-37; that model class has no post_projector_pooling):
+      normalize(frames * 1/255, .5, .5) -> vision_model(frames).last_hidden_state (= tower + post_layernorm,
+      transformers modeling_siglip.py:622-644) -> adaptive_avg_pool2d over the patch grid -> connector.
+    Returns [N*ph*pw, H]."""
+    dt, v = ov.dtype, ov.v
+    x = ov.tower(preprocess(frames_u8, dt))
+    x = F.layer_norm(x, (v.hidden_size,), post_ln_w.to(dt), post_ln_b.to(dt), v.layer_norm_eps)
+    n, _, d = x.shape
+    s = int(math.sqrt(x.shape[1]))
+    sp = F.adaptive_avg_pool2d(x.reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))
+    sp = sp.flatten(2, 3).permute(0, 2, 1)
+    y = ov.connector(sp)
+    return y.reshape(-1, y.shape[-1])

@@ -455,3 +455,27 @@ def test_long_sink_stream_bookkeeping_and_reproducibility(bench_rt):
         runs.append(sc)
         st.close()
     assert torch.equal(runs[0], runs[1])
+
+
+def test_vision_live_contract_pooled_first():
+    """The SigLIP encode contract of models/vision_live.py (the file the north star names; dead code for
+    the shipped model): post_layernorm + adaptive_avg_pool2d(27x27 -> 7x7, ragged windows) + connector."""
+    from aha_amd.config import LiveConfig, LMConfig, VisionConfig
+    from oracle.vision_tower import OracleVision, vision_live_encode
+    cfg = LiveConfig(vision=VisionConfig(image_size=378, patch_size=14, hidden_size=128, num_hidden_layers=2,
+                                         num_attention_heads=2, intermediate_size=256),
+                     lm=LMConfig(hidden_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2,
+                                 head_dim=64, intermediate_size=512, vocab_size=512), name="vlive")
+    assert cfg.vision.grid == 27
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    g = torch.Generator().manual_seed(3)
+    w["vision.post_layernorm.weight"] = (1 + 0.1 * torch.randn(128, generator=g)).bfloat16()
+    w["vision.post_layernorm.bias"] = (0.02 * torch.randn(128, generator=g)).bfloat16()
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=2, max_positions=1024)
+    fr = make_frames(2, 378, seed=4)
+    want = vision_live_encode(OracleVision(cfg, w, torch.bfloat16), fr, w["vision.post_layernorm.weight"],
+                              w["vision.post_layernorm.bias"], (7, 7)).float()
+    got = rt.vision_live_embed(fr.cuda(), pooled=7).float().cpu()
+    assert got.shape == want.shape == (2 * 49, 256)
+    assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
+    rt.close()
