@@ -39,6 +39,7 @@ def parse():
     p.add_argument("--cache", default="static", choices=["static", "default_sink", "sliding_window", "none"])
     p.add_argument("--window", type=int, default=2048)
     p.add_argument("--sink", type=int, default=32)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side collective (rehearsal)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
@@ -112,12 +113,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    local = local % max(1, torch.cuda.device_count())            # --backend gloo rehearsal: several ranks on one GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if a.backend == "nccl":                                   # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    from aha_amd.sharding import gather_scores
     from aha_amd.runtime import Runtime
 
     cfg = preset(a.preset)
@@ -140,7 +146,7 @@ def main():
     streams = [rt.open_stream(cache, a.window, a.sink, capacity=cfg.lm.max_position_embeddings) for _ in range(B)]
     scores_host = torch.empty((F, B, 3), dtype=torch.float32).pin_memory()
     scores_dev = torch.empty((F, B, 3), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, F, B, 3), dtype=torch.float32, device=dev) if world > 1 else None
+    n_streams_global = B * world                                  # stream g lives on rank g % world
 
     # stream prologue (untimed): query turn first (test/inference.py:294-298), then system prompt + frame 0
     q = rt.embed_tokens(query_ids).view(1, -1, H).expand(B, -1, -1).contiguous()
@@ -182,7 +188,9 @@ def main():
                 scores_dev[i] = rt.lm_step(streams, emb[:, i].contiguous())
             emb_free[k & 1].record(main_stream)
             if world > 1:
-                dist.all_gather_into_tensor(gathered.view(-1), scores_dev.view(-1))
+                # one collective per step on [F, B, 3] score rows -> [F, B*world, 3] in global stream order
+                loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
+                run.last_global = gather_scores(loc, n_streams_global)
             scores_host.copy_(scores_dev, non_blocking=True)
 
     def sync():
@@ -199,8 +207,9 @@ def main():
     dt = time.perf_counter() - t0
     rt.set_tuning("time_gemm", 0)
     if world > 1:
-        t = torch.tensor([dt], device=dev)
+        t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert run.last_global.shape == (F, n_streams_global, 3) and torch.isfinite(run.last_global).all()
         dt = t.item()
     assert torch.isfinite(scores_host).all()
 
@@ -268,7 +277,7 @@ def main():
                                    f"{B} stream(s)/GPU, {a.cache} KV cache (W={a.window}), {F} frames/stream/step, "
                                    f"Tf={tf} tokens/frame, seeded random weights",
                        "frames_per_step": F * B * world, "streams_per_gpu": B, "cache": a.cache, "vit_lm_overlap": not a.no_overlap,
-                       "parallelism": f"stream-sharded x{world}" + (", RCCL all-gather of scores" if world > 1 else "")},
+                       "parallelism": f"stream-sharded x{world}" + (f", {'RCCL' if a.backend == 'nccl' else 'gloo'} all-gather of scores" if world > 1 else "")},
             "p50_frame_latency_ms": lat[len(lat) // 2],
             "roofline": {"bound": "hbm", "kernel": "gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
