@@ -457,6 +457,19 @@ def test_long_sink_stream_bookkeeping_and_reproducibility(bench_rt):
     assert torch.equal(runs[0], runs[1])
 
 
+def test_lds_dma_gemm_matches_register_staged_gemm(bench_rt):
+    """The LDS-DMA tile GEMM (256x128, 3 stages, counted vmcnt) is selected automatically for large M; forced here
+    on 3 frames (M = 1728) it must reproduce the register-staged kernel bit for bit (same k order per element)."""
+    cfg, rt = bench_rt
+    fr = make_frames(3, cfg.vision.image_size, seed=21).cuda()
+    outs = []
+    for mode in (0, 2):
+        rt.set_tuning("tile_dma", mode)
+        outs.append(rt.visual_embed(fr).clone())
+    rt.set_tuning("tile_dma", 1)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[1].float()).all()
+
+
 def test_vision_live_contract_pooled_first():
     """The SigLIP encode contract of models/vision_live.py (the file the north star names; dead code for
     the shipped model): post_layernorm + adaptive_avg_pool2d(27x27 -> 7x7, ragged windows) + connector."""
