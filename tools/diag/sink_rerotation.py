@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo' if __import__('os').path.isdir('/root/repo') else '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import aha_amd
 from aha_amd.config import preset
 from aha_amd.synth import make_weights

@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import aha_amd
 from aha_amd.config import preset
 from aha_amd.synth import make_weights
