@@ -81,6 +81,7 @@ struct aha_stream {
     bf16 *k = nullptr, *v = nullptr;
     int len = 0, head = 0, seen = 0;
     int semantics = AHA_ATTN_TRAILING;
+    int pos_off = 0;                     // added to the RoPE position of new token 0 (aha_stream_set_position_offset)
 };
 
 static int fail(aha_ctx* c, int code, const std::string& msg) {
@@ -420,6 +421,11 @@ extern "C" int aha_stream_set_attn_semantics(aha_stream* s, int sem) {
     s->semantics = sem;
     return 0;
 }
+extern "C" int aha_stream_set_position_offset(aha_stream* s, int offset) {
+    if (!s || offset < 0) return AHA_E_INVAL;
+    s->pos_off = offset;
+    return 0;
+}
 extern "C" void aha_stream_destroy(aha_stream* s) {
     if (!s) return;
     hipSetDevice(s->ctx->device);
@@ -439,7 +445,7 @@ static int plan_stream(aha_ctx* c, aha_stream* s, int T, StreamStep* o) {
     o->k_base = s->k;
     o->v_base = s->v;
     o->cap = s->cap;
-    o->pos_base = L;
+    o->pos_base = L + s->pos_off;
     o->ring_cap = 1;
     o->write_count = T;
     int new_len = L, new_head = s->head;

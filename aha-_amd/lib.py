@@ -53,6 +53,7 @@ SYMBOLS = [
     ("aha_stream_seq_length", _I, [_P]),
     ("aha_stream_seen_tokens", _I, [_P]),
     ("aha_stream_set_attn_semantics", _I, [_P, _I]),
+    ("aha_stream_set_position_offset", _I, [_P, _I]),
     ("aha_stream_export_kv", _I, [_P, _P, _I, _I, _P, _P]),
     ("aha_stream_destroy", None, [_P]),
     ("aha_lm_step", _I, [_P, C.POINTER(_P), _I, _P, _I, _P, _P, _P, _P]),

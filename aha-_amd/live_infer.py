@@ -254,14 +254,26 @@ class LiveInferForBenchmark:
         return response
 
     # ---- test/inference.py:283-335 ---------------------------------------------------------------
-    def _encode_frames_static_batched(self, frames_per_step: int):
+    def _encode_frames_static_batched(self, frames_per_step: int, last_token_only: bool = False):
         """TrulyStaticCache only: once the cache is frozen a frame's scores do not depend on any other
         frame (test/static_cache.py:26-36), so `frames_per_step` queued frames are scored with ONE pass over
         the weights (the frozen stream is listed once per frame).  Bit-identical to scoring them one by
         one; used by inference() only while no query / prompt prefix has to be interleaved."""
         g = min(frames_per_step, len(self.frame_embeds_queue))
         embeds = torch.stack([self.frame_embeds_queue.popleft()[1] for _ in range(g)]).view(g, -1, self.hidden_size)
-        scores = self.rt.lm_step([self.past_key_values] * g, embeds).tolist()
+        if last_token_only:
+            # Under the frozen static cache a new token attends ONLY to the prefix (never to the other
+            # tokens of its own frame), and the drivers read the heads at position -1 only
+            # (test/inference.py:222-227): the other T-1 tokens of a frame cannot influence its scores.
+            # Feed just the last token, at the RoPE position it would have had.  Opt-in, bit-identical.
+            T = embeds.shape[1]
+            self.past_key_values.set_position_offset(T - 1)
+            try:
+                scores = self.rt.lm_step([self.past_key_values] * g, embeds[:, -1:].contiguous()).tolist()
+            finally:
+                self.past_key_values.set_position_offset(0)
+        else:
+            scores = self.rt.lm_step([self.past_key_values] * g, embeds).tolist()
         self.frame_idx += g
         self.num_frames_no_reply += g
         self.last_role = "stream"
@@ -269,7 +281,7 @@ class LiveInferForBenchmark:
         return scores
 
     @torch.no_grad()
-    def inference(self, verbose=False, total=None, frames_per_step: int = 1):
+    def inference(self, verbose=False, total=None, frames_per_step: int = 1, static_last_token_only: bool = False):
         model_response_list = [{"time": q[0], "content": q[1], "role": "user"} for q in self.query_queue]
         pending = collections.deque()        # scores already computed by a static batched step
         while self.frame_embeds_queue or pending:
@@ -281,7 +293,7 @@ class LiveInferForBenchmark:
                          and self.last_role == "stream" and self.past_key_values.get_seq_length() > 0
                          and not (self.query_queue and self.query_queue[0][0] <= self.video_time + (frames_per_step - 1) / self.frame_fps))
             if not pending and can_batch and len(self.frame_embeds_queue) > 1:
-                pending.extend(self._encode_frames_static_batched(frames_per_step))
+                pending.extend(self._encode_frames_static_batched(frames_per_step, static_last_token_only))
             if pending:
                 s = pending.popleft()
                 video_scores, uncertainty_score = {"informative_score": s[0], "relevance_score": s[1]}, s[2]

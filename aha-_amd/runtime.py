@@ -64,6 +64,9 @@ class Stream:
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.rt.lib.aha_stream_seq_length(self.handle)
 
+    def set_position_offset(self, offset: int):
+        self.rt._chk(self.rt.lib.aha_stream_set_position_offset(self.handle, int(offset)))
+
     @property
     def seen_tokens(self) -> int:
         return self.rt.lib.aha_stream_seen_tokens(self.handle)
@@ -111,15 +114,19 @@ class Runtime:
             pool_mode=_POOL_MODE[cfg.mm_spatial_pool_mode], max_step_tokens=max_step_tokens, max_vit_frames=max_vit_frames)
         ctx = C.c_void_p()
         rc = self.lib.aha_ctx_create(C.byref(self.desc), self.device.index or 0, C.byref(ctx))
-        self.ctx = ctx
-        self._chk(rc)
-        self._load(weights)
-        cos, sin = rope_table(self.desc.max_positions, lm.head_dim, lm.rope_theta)
-        self._rope_cpu = (cos, sin)
-        cd, sd = cos.to(self.device), sin.to(self.device)
-        self._chk(self.lib.aha_ctx_set_rope_table(self.ctx, cd.data_ptr(), sd.data_ptr(), cos.shape[0], _cur_stream()))
+        self.ctx = ctx if ctx.value else None
         self.frame_num_tokens = cfg.frame_num_tokens
         self.hidden_size = lm.hidden_size
+        try:
+            self._chk(rc)
+            self._load(weights)
+            cos, sin = rope_table(self.desc.max_positions, lm.head_dim, lm.rope_theta)
+            self._rope_cpu = (cos, sin)
+            cd, sd = cos.to(self.device), sin.to(self.device)
+            self._chk(self.lib.aha_ctx_set_rope_table(self.ctx, cd.data_ptr(), sd.data_ptr(), cos.shape[0], _cur_stream()))
+        except Exception:
+            self.close()                 # a half-built context must not leak its device allocations
+            raise
 
     # -- plumbing -------------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -152,6 +159,12 @@ class Runtime:
         if self.ctx is not None:
             self.lib.aha_ctx_destroy(self.ctx)
             self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- streams ---------------------------------------------------------------------------------
     def open_stream(self, alt_cache: Optional[str] = "default_sink", window_length: int = 2048, num_sink_tokens: int = 32,

@@ -255,6 +255,27 @@ def main():
         dtb = time.perf_counter() - t1
         static_batched = {"frames_per_lm_step": G, "frames_per_s": F * a.steps / dtb, "ms_per_step": dtb / a.steps * 1e3,
                           "max_abs_score_diff_vs_sequential": max_dev}    # 0.0: bit-identical
+        # second observation (also NOT `value`): under the frozen static cache a new token attends only to the prefix,
+        # so the scores read at position -1 do not depend on the other tf-1 tokens of the frame; feeding only each
+        # frame's last token (at its RoPE position) is bit-identical and makes the step vision-bound.
+        def step_last_token():
+            emb = rt.visual_embed(frames_all).view(F, tf, H)
+            streams[0].set_position_offset(tf - 1)
+            for i in range(0, F, 16):                                 # at most 16 streams per aha_lm_step
+                g = min(16, F - i)
+                scores_dev[i:i + g, 0] = rt.lm_step(streams * g, emb[i:i + g, -1:].contiguous())
+            streams[0].set_position_offset(0)
+            scores_host.copy_(scores_dev, non_blocking=True)
+        step_last_token()
+        sync()
+        max_dev2 = (scores_host - ref).abs().max().item()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            step_last_token()
+        sync()
+        dtl = time.perf_counter() - t2
+        static_batched["last_token_only"] = {"frames_per_s": F * a.steps / dtl, "ms_per_step": dtl / a.steps * 1e3,
+                                             "max_abs_score_diff_vs_sequential": max_dev2}
 
     # per-kind GEMM breakdown of one LM step (diagnostic, outside the timed region)
     rt.set_tuning("time_gemm", 15)

@@ -103,6 +103,10 @@ int aha_stream_reset(aha_stream* s);                       /* LiveInferForBenchm
 int aha_stream_seq_length(const aha_stream* s);            /* Cache.get_seq_length()      */
 int aha_stream_seen_tokens(const aha_stream* s);           /* Cache._seen_tokens          */
 int aha_stream_set_attn_semantics(aha_stream* s, int semantics);
+/* RoPE position of the next steps' new token 0 = seq_length + offset (default 0 = the reference's
+ * `cache_position` rule).  Lets a caller that feeds only the tail of a chunk keep the positions the
+ * whole chunk would have had (aha_amd.live_infer static last-token mode). */
+int aha_stream_set_position_offset(aha_stream* s, int offset);
 /* test tap: copy layer `layer`'s K or V as the attention sees it (logical order) into
  * out bf16 [kv_heads][seq_len][head_dim] */
 int aha_stream_export_kv(aha_ctx* ctx, const aha_stream* s, int layer, int want_v, void* out, aha_hip_stream st);

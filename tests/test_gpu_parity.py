@@ -441,6 +441,36 @@ def test_driver_static_batched_equals_sequential(tiny):
     assert out[0] == out[1] and len(out[0]) == 11
 
 
+def test_static_last_token_only_is_bit_identical(tiny128, bench_rt):
+    """Frozen TrulyStaticCache: a new token sees only the prefix, so the scores read at position -1 cannot
+    depend on the other tokens of the frame; feeding the last token alone (at its RoPE position) must give
+    the same bits.  Driver level (tiny) and raw step level on the full model."""
+    from aha_amd.arguments import LiveTestArguments
+    from aha_amd.live_infer import LiveInferForBenchmark
+    cfg, w, rt = tiny128
+    frames = make_frames(9, cfg.vision.image_size, seed=13)
+    out = []
+    for last_only in (False, True):
+        drv = LiveInferForBenchmark(LiveTestArguments(frame_fps=1, stream_end_prob_threshold=9.0), alt_cache="static", runtime=rt)
+        drv.input_video_stream(frames)
+        drv.input_query_stream([{"role": "user", "content": "anything new", "time": 0}])
+        drv.inference(frames_per_step=4, static_last_token_only=last_only)
+        out.append(drv.debug_data_list)
+    assert out[0] == out[1] and len(out[0]) == 9
+    cfg, rt = bench_rt
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    g = torch.Generator().manual_seed(14)
+    st = rt.open_stream("static", 2048, 0)
+    rt.lm_step([st], (torch.randn(1, 20, H, generator=g) * 0.1).bfloat16().cuda())
+    x = (torch.randn(3, tf, H, generator=g) * 0.1).bfloat16().cuda()
+    full = rt.lm_step([st] * 3, x).cpu()
+    st.set_position_offset(tf - 1)
+    tail = rt.lm_step([st] * 3, x[:, -1:].contiguous()).cpu()
+    st.set_position_offset(0)
+    assert torch.equal(full, tail)
+    st.close()
+
+
 def test_long_sink_stream_bookkeeping_and_reproducibility(bench_rt):
     """configs[2] in small: 150 frames through SinkCache(W=2048, sink=32) on the full model, twice."""
     cfg, rt = bench_rt
