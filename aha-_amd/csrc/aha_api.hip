@@ -37,7 +37,7 @@ struct aha_ctx {
     aha_model_desc d;
     int device = 0;
     std::string err;
-    int grid = 0, Np = 0, Kp = 0, go = 0, Tf = 0;
+    int grid = 0, Np = 0, Kp = 0, Fp = 0, go = 0, Tf = 0;   // Kp / Fp: patch-vector / MLP width padded to whole 64-wide k-tiles
     bool weights_loaded = false;
     // LM weights
     std::vector<LayerW> L;
@@ -130,7 +130,10 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if (d->hidden > 8192) return fail(c, AHA_E_INVAL, "hidden > 8192 unsupported");
     c->grid = d->image_size / d->patch_size;
     c->Np = c->grid * c->grid;
-    c->Kp = round_up(3 * d->patch_size * d->patch_size, 8);
+    // K of the patch embedding (3*P*P = 588) and of fc2 (so400m: 4304) padded with zeros to whole k-tiles so that
+    // every tower GEMM is eligible for the LDS-DMA kernels (gemm_tile.hip); zero columns add exact zeros.
+    c->Kp = round_up(3 * d->patch_size * d->patch_size, 64);
+    c->Fp = round_up(d->v_inter, 64);
     c->go = d->pool_mode == 0 ? ceil_div(c->grid, d->pool_stride) : c->grid / d->pool_stride;
     c->Tf = c->go * c->go;
 
@@ -160,7 +163,9 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if ((rc = dalloc(c, &c->v_h, R * Dv))) return rc;
     if ((rc = dalloc(c, &c->v_qkv, R * 3 * Dv))) return rc;
     if ((rc = dalloc(c, &c->v_attn, R * Dv))) return rc;
-    if ((rc = dalloc(c, &c->v_f, R * d->v_inter))) return rc;
+    if ((rc = dalloc(c, &c->v_f, R * c->Fp))) return rc;
+    if (hipMemset(c->v_f, 0, R * c->Fp * sizeof(bf16)) != hipSuccess)       // pad columns stay zero: fc1 writes n < v_inter only
+        return fail(c, AHA_E_NOMEM, "hipMemset failed");
     if ((rc = dalloc(c, &c->v_p1, R * H))) return rc;
     if ((rc = dalloc(c, &c->v_p2, R * H))) return rc;
     return 0;
@@ -328,7 +333,14 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
         if ((rc = copy_vec(c, m, p + "self_attn.out_proj.bias", Dv, &w.bo, st))) return rc;
         if ((rc = copy_vec(c, m, p + "mlp.fc1.weight", (int64_t)d.v_inter * Dv, &w.w1, st))) return rc;
         if ((rc = copy_vec(c, m, p + "mlp.fc1.bias", d.v_inter, &w.b1, st))) return rc;
-        if ((rc = copy_vec(c, m, p + "mlp.fc2.weight", (int64_t)Dv * d.v_inter, &w.w2, st))) return rc;
+        {
+            const aha_tensor_view* t = need(c, m, p + "mlp.fc2.weight", 2, Dv, d.v_inter);
+            if (!t) return AHA_E_NOENT;
+            if ((rc = dalloc(c, &w.w2, (size_t)Dv * c->Fp))) return rc;
+            HIPCHK(c, hipMemsetAsync(w.w2, 0, (size_t)Dv * c->Fp * 2, st));
+            HIPCHK(c, hipMemcpy2DAsync(w.w2, (size_t)c->Fp * 2, t->data, (size_t)d.v_inter * 2, (size_t)d.v_inter * 2, Dv,
+                                       hipMemcpyDeviceToDevice, st));
+        }
         if ((rc = copy_vec(c, m, p + "mlp.fc2.bias", Dv, &w.b2, st))) return rc;
     }
     if (m.count("vision.post_layernorm.weight") && m.count("vision.post_layernorm.bias")) {
@@ -571,8 +583,8 @@ static int vit_tower(aha_ctx* c, const uint8_t* frames, int n, hipStream_t st) {
         HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
         HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
         HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, d.v_inter, w.b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
-        HIPCHK(c, tile_gemm(c->v_f, d.v_inter, rows, w.w2, d.v_inter, Dv, d.v_inter, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
+        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, w.b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, tile_gemm(c->v_f, c->Fp, rows, w.w2, c->Fp, Dv, c->Fp, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
     }
     return 0;
 }

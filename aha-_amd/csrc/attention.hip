@@ -7,12 +7,13 @@
 //
 // Structure (gfx950, wave64):  a workgroup = 4 waves owns one (kv head, 64-row group, key split);
 // each wave owns ONE 16-row query tile.  Per 64-key block the workgroup stages K (row-major,
-// 16-B chunks XOR-swizzled => conflict-free ds_read_b128) and V (transposed, padded) in LDS, then
+// 16-B chunks XOR-swizzled => conflict-free ds_read_b128) and V (row-major, rows padded by 32 B) in LDS, then
 // each wave computes  S^T = K * Q^T  with v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows kept
 // in registers), so a lane holds scores of ONE query row (lane&15) for 4 consecutive keys per
 // key tile: the softmax row reduction is in-register + two xor-shuffles (16, 32), and the
 // exponentiated tile, packed to bf16, IS the B operand of  O^T += V^T * P^T  with no LDS round
-// trip (the k-slot permutation is absorbed by reading V^T as two 8-byte halves).
+// trip (the k-slot permutation is absorbed by fetching the V^T fragment as two transposed 4-key reads,
+// ds_read_b64_tr_b16).
 // Online softmax in fp32; P rounded to bf16 before PV (flash/sdpa semantics).  With more than
 // one key split the kernel writes (m, l, unnormalised O) partials and attn_combine merges them.
 #include "aha_kernels.h"
@@ -20,7 +21,8 @@
 
 template <int D> struct AttnCfg {
     static constexpr int CPR = D / 8;          // 16-B chunks per K row
-    static constexpr int VST = 68;             // V^T row stride in elements (64 keys + 4 pad)
+    static constexpr int VST = D + 16;         // V row stride in elements: 2*D + 32 bytes, so the 8 rows a 32-lane half
+                                               // touches in one transposed read start 8 banks apart (conflict-free)
     static constexpr int DT = D / 16;          // d-tiles of the output
     static constexpr int KSQ = D / 32;         // k-steps of the QK^T product
 };
@@ -29,7 +31,7 @@ template <int D, bool LM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) {
     using C = AttnCfg<D>;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
-    __shared__ __attribute__((aligned(16))) bf16 Vt[D * C::VST];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q4 = lane >> 4, r16 = lane & 15;
@@ -136,27 +138,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
     for (int i = 0; i < C::DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int jb = j0; jb < j1; jb += 64) {
-        __syncthreads();                                    // previous block's LDS reads done
-        // ---- stage K (swizzled rows) and V (transposed) for keys jb .. jb+63
+    // K/V staging is issue-early / write-late with TWO key blocks in flight: register sets A and B hold blocks
+    // jb+64 and jb+128 while block jb computes, so a workgroup's chain of key blocks (9 for one ViT frame, where
+    // only 144 workgroups exist and nothing else hides the latency) no longer exposes one load latency per block.
+    // Loads are unconditional with clamped indices (finite data; masked below / zeroed at the store), the loop is
+    // unrolled by two so each set is statically indexed (counted vmcnt), and a trailing block that lies wholly past
+    // j1 is an exact no-op of the online softmax (all scores -inf: alpha = 1, p = 0).
+    constexpr int NCH = (64 * C::CPR) / 256;
+    bf16x8 kA[NCH], vA[NCH], kB[NCH], vB[NCH];
+    auto gload = [&](bf16x8 (&kreg)[NCH], bf16x8 (&vreg)[NCH], int jb) {
 #pragma unroll
-        for (int i = 0; i < (64 * C::CPR) / 256; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             const int idx = tid + i * 256;
             const int row = idx / C::CPR, ch = idx % C::CPR;
-            int j = jb + row; if (j > j1 - 1) j = j1 - 1;  // clamp: finite data, masked below
+            int j = jb + row; if (j > j1 - 1) j = j1 - 1;
             int slot = j;
             if constexpr (LM) slot = phys_slot(ss, j);
             const int dch = min(ch * 8, a.hd - 8);
-            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (long)slot * ldk + dch);
-            bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (long)slot * ldk + dch);
-            if (ch * 8 >= a.hd) { kv = z8; vv = z8; }
-            *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
+            kreg[i] = *reinterpret_cast<const bf16x8*>(kb + (long)slot * ldk + dch);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(vb + (long)slot * ldk + dch);
+        }
+    };
+    auto block = [&](bf16x8 (&kreg)[NCH], bf16x8 (&vreg)[NCH], int jb) {
+        __syncthreads();                                    // previous block's LDS reads done
+        // ---- stage K (swizzled rows) and V (transposed) for keys jb .. jb+63 from the prefetched registers
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * C::VST + row] = vv[e];
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const bool pad = ch * 8 >= a.hd;
+            const bf16x8 kv = pad ? z8 : kreg[i], vv = pad ? z8 : vreg[i];
+            *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
+            *reinterpret_cast<bf16x8*>(&Vs[row * C::VST + ch * 8]) = vv;
         }
         __syncthreads();
-        if (!wave_on) continue;
+        gload(kreg, vreg, jb + 128);                        // refill this set two blocks ahead
+        if (!wave_on) return;
 
         // ---- S^T tiles: acc[kt][e] = score(key jb + kt*16 + 4*q4 + e, row r)
         f32x4 s[4];
@@ -206,18 +224,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int i = 0; i < C::DT; ++i) o[i] *= alpha;
-        // ---- O^T += V^T * P^T ; k-slot (q4, e): e<4 -> key (2kp)*16+4q4+e, e>=4 -> key (2kp+1)*16+4q4+e-4
+        // ---- O^T += V^T * P^T ; k-slot (q4, e): e<4 -> key (2kp)*16+4q4+e, e>=4 -> key (2kp+1)*16+4q4+e-4.
+        // V sits row-major in LDS; ds_read_b64_tr_b16 hands lane r16 of each 16-lane group column dt*16+r16 of the
+        // group's 4-key block (lane 4q+p supplies the address of block row q, columns 4p..4p+3), i.e. exactly the
+        // V^T fragment, with no transposing store.  All 64 lanes are active here (wave_on is per wave).
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        const int vrow = 4 * q4 + (r16 >> 2), vcol = 4 * (r16 & 3);
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
-            const int drow = dt * 16 + r16;
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(&Vt[drow * C::VST + (2 * kp) * 16 + 4 * q4]);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(&Vt[drow * C::VST + (2 * kp + 1) * 16 + 4 * q4]);
-                const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[((2 * kp) * 16 + vrow) * C::VST + dt * 16 + vcol]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[((2 * kp + 1) * 16 + vrow) * C::VST + dt * 16 + vcol]));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 o[dt] = mfma16(vf, pb[kp], o[dt]);
             }
         }
+    };
+    gload(kA, vA, j0);
+    __builtin_amdgcn_sched_barrier(0);                      // keep set A's loads older than set B's (counted vmcnt at the loop top)
+    gload(kB, vB, j0 + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int jb = j0; jb < j1; jb += 128) {
+        block(kA, vA, jb);
+        block(kB, vB, jb + 64);
     }
     if (!wave_on) return;
     // row sum across the 4 lanes that share this query row

@@ -163,132 +163,183 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant for the throughput shapes (M >= 1024, K % 64 == 0): 256x128 block tile, 8 waves
-// (4 x 2, each 64x64), THREE 48 KB stages filled by global_load_lds_dwordx4 (no staging VGPRs, so
-// two k-tiles are in flight while one computes - the register-staged kernel above can only keep
-// one, and a second register set spills).  Per k-tile: counted `s_waitcnt vmcnt(6)` (this wave's
-// six DMA pieces of tile kt have landed, tile kt+1 stays in flight) -> raw s_barrier (everyone's
-// pieces landed; everyone finished reading the stage about to be refilled) -> issue tile kt+2 ->
-// ds_read + MFMA on tile kt.  LDS image = the same 128-B rows with the chunk index XOR-swizzled by
-// (row & 7); an LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE address
-// (guide rule 21).  One __shared__ object only; no ordinary global loads inside the loop.
+// LDS-DMA family (K % 64 == 0): block tile BM x BN = (WAVES_M*16*WI) x (WAVES_N*16*WJ), one wave per
+// (16*WI) x (16*WJ) sub-tile, STAGES stages of (BM+BN) 128-byte rows filled by global_load_lds_dwordx4
+// (no staging VGPRs, so STAGES-1 k-tiles are in flight while one computes - the register-staged kernel
+// above keeps one, and a second register set spills).  Per k-tile: counted `s_waitcnt vmcnt((STAGES-2)*P)`
+// (this wave's P DMA pieces of tile kt have landed, the younger tiles stay in flight) -> raw s_barrier
+// (everyone's pieces landed; everyone finished reading the stage about to be refilled) -> issue tile
+// kt+STAGES-1 -> ds_read + MFMA on tile kt.  LDS image = the same 128-B rows with the chunk index
+// XOR-swizzled by (row & 7); an LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE
+// address (guide rule 21).  One __shared__ object only; no ordinary global loads inside the loop.
+//   <4,4,4,2,3>  256x128, 8 waves, 3 x 48 KB : throughput shapes (grids that fill their last round of CUs); ILV = the
+//                DMA pieces of tile kt+2 issued between the MFMAs of tile kt instead of in a bunch after the barrier
+//   <2,4,4,2,4>  128x128, 8 waves, 4 x 32 KB : (sweeps only: wins two mid-M shapes by < 10 %)
+//   <2,2,2,2,4>   64x64,  4 waves, 4 x 16 KB : (sweeps only)
+//   <2,2,2,2,3>   64x64,  4 waves, 3 x 16 KB : everything smaller, down to one frame (3 workgroups per CU)
+// Every variant accumulates one output element's k-tiles in the same order, so they are bit-identical to each
+// other and to gemm_tile_kernel (tests/test_gpu_parity.py).
 // ---------------------------------------------------------------------------------------------
-#define DBM 256
-#define DBN 128
-#define DSTAGES 3
-
-__global__ __launch_bounds__(512, 2) void gemm_tile_dma_kernel(GemmTileArgs g) {
+template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES, bool ILV = false>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tile_dma_kernel(GemmTileArgs g) {
+    constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ, NT = 64 * WAVES_M * WAVES_N;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * TBK;              // elements per stage
+    constexpr int P = ROWS * 8 / NT;                                // 16-B DMA pieces per thread per stage
+    static_assert(ROWS * 8 % NT == 0, "stage image must split evenly over the threads");
+    static_assert((STAGES - 2) * P <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
     bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
-    constexpr int STAGE = (DBM + DBN) * TBK;                       // elements per stage
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, r16 = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    const int tiles_n = ceil_div(g.N, DBN), tiles_m = ceil_div(g.M, DBM);
+    const int tiles_n = ceil_div(g.N, BN), tiles_m = ceil_div(g.M, BM);
     const int nblk = tiles_n * tiles_m;
     int bid = blockIdx.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    // Grouped rasterisation: consecutive ids walk 4 m-panels x all n-tiles column by column, so the ~32
-    // workgroups one XCD runs together share 4 A panels and ~8 W panels (fits its 4 MB L2).  With plain row-major
-    // order they shared 1 A panel and 32 W panels (8 MB of W): W thrashed L2 and streamed from Infinity Cache
-    // (measured: waves parked ~45 % on vmcnt/barrier, zero LDS conflicts).
-    constexpr int GROUP_M = 4;
+    // Grouped rasterisation: consecutive ids walk GROUP_M m-panels x all n-tiles column by column, so the ~32
+    // workgroups one XCD runs together share a few A panels and a few W panels (fits its 4 MB L2).  With plain
+    // row-major order they shared 1 A panel and 32 W panels (8 MB of W): W thrashed L2 and streamed from Infinity
+    // Cache (measured: waves parked ~45 % on vmcnt/barrier, zero LDS conflicts).
+    constexpr int GROUP_M = BM >= 256 ? 4 : 8;
     const int per_group = GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * GROUP_M;
     const int gmn = min(tiles_m - first_m, GROUP_M), inner = bid % per_group;
     const int bm = first_m + inner % gmn, bn = inner / gmn;
-    const int m0 = bm * DBM, n0 = bn * DBN;
+    const int m0 = bm * BM, n0 = bn * BN;
     const int nk = g.K / TBK;
 
-    f32x4 acc[4][4];
+    f32x4 acc[WI][WJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // DMA piece p of a stage = 512 consecutive 16-B chunks of the stage image (chunk c -> row c/8,
-    // slot c%8); lane's source chunk = slot ^ (row & 7).  A: 4 pieces, W: 2 pieces per thread.
-    int aoff[4], woff[2];
+    // DMA piece p of a stage = NT consecutive 16-B chunks of the stage image (chunk c -> row c/8, slot c%8;
+    // rows [0,BM) come from A, rows [BM,ROWS) from W); a lane's source chunk = slot ^ (row & 7).
+    const bf16* src[P];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = i * 512 + tid, row = c >> 3, ch = (c & 7) ^ (row & 7);
-        aoff[i] = min(m0 + row, g.M - 1) * g.lda + ch * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = i * 512 + tid, row = c >> 3, ch = (c & 7) ^ (row & 7);
-        woff[i] = min(n0 + row, g.N - 1) * g.ldw + ch * 8;
+    for (int i = 0; i < P; ++i) {
+        const int c = i * NT + tid, row = c >> 3, ch = (c & 7) ^ (row & 7);
+        src[i] = row < BM ? g.A + min(m0 + row, g.M - 1) * g.lda + ch * 8
+                          : g.W + min(n0 + row - BM, g.N - 1) * g.ldw + ch * 8;
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto dma = [&](int kt, int stage) {
         const int k0 = min(kt, nk - 1) * TBK;                      // past the end: refill a dead stage (keeps vmcnt counts fixed)
         bf16* sa = lds + stage * STAGE;
-        bf16* sb = sa + DBM * TBK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.A + aoff[i] + k0), (lptr_t)(sa + (i * 512 + wave * 64) * 8), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g.W + woff[i] + k0), (lptr_t)(sb + (i * 512 + wave * 64) * 8), 16, 0, 0);
+        for (int i = 0; i < P; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + k0), (lptr_t)(sa + (i * NT + wave * 64) * 8), 16, 0, 0);
     };
     auto compute = [&](int stage) {
         const bf16* sa = lds + stage * STAGE;
-        const bf16* sb = sa + DBM * TBK;
+        const bf16* sb = sa + BM * TBK;
 #pragma unroll
         for (int ks = 0; ks < TBK / 32; ++ks) {
-            bf16x8 af[4], wf[4];
+            bf16x8 af[WI], wf[WJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + r16;
+            for (int i = 0; i < WI; ++i) {
+                const int row = wm * (16 * WI) + i * 16 + r16;
                 af[i] = *reinterpret_cast<const bf16x8*>(&sa[row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
-                const int wrow = wn * 64 + i * 16 + r16;
-                wf[i] = *reinterpret_cast<const bf16x8*>(&sb[wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < WJ; ++j) {
+                const int wrow = wn * (16 * WJ) + j * 16 + r16;
+                wf[j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+            for (int i = 0; i < WI; ++i)
+#pragma unroll
+                for (int j = 0; j < WJ; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
     };
 
-    dma(0, 0);
-    dma(1, 1);
-    int st_cur = 0, st_new = 2;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) dma(s, s);
+    int st_cur = 0, st_new = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // tile kt (this wave's pieces) landed; kt+1 in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");   // tile kt (this wave's pieces) landed
         __builtin_amdgcn_s_barrier();
-        dma(kt + 2, st_new);
-        compute(st_cur);
-        st_cur = st_cur == 2 ? 0 : st_cur + 1;
-        st_new = st_new == 2 ? 0 : st_new + 1;
+        if constexpr (!ILV) {
+            dma(kt + STAGES - 1, st_new);
+            compute(st_cur);
+        } else {
+            // Interleaved issue: every fragment read of the k-tile first, then the DMA pieces of tile kt+STAGES-1 spread
+            // between the MFMAs (a piece issued while the MFMA pipe is busy costs ~60 cycles; bunched after the barrier,
+            // where both waves of a SIMD stand at the same point, 100-185 each with nothing to overlap).  The pieces
+            // sit between the MFMA groups in SOURCE order (hipcc does not move an LDS-DMA across a ds_read) and the
+            // group barriers keep the MFMAs from clumping.
+            constexpr int KS = TBK / 32, NM = WI * WJ * KS, PER = NM / (P + 1);
+            const bf16* sa = lds + st_cur * STAGE;
+            const bf16* sb = sa + BM * TBK;
+            bf16* sn = lds + st_new * STAGE;
+            const int k0 = min(kt + STAGES - 1, nk - 1) * TBK;
+            bf16x8 af[KS][WI], wf[KS][WJ];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < WI; ++i) {
+                    const int row = wm * (16 * WI) + i * 16 + r16;
+                    af[ks][i] = *reinterpret_cast<const bf16x8*>(&sa[row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
+                }
+#pragma unroll
+                for (int j = 0; j < WJ; ++j) {
+                    const int wrow = wn * (16 * WJ) + j * 16 + r16;
+                    wf[ks][j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < WI; ++i)
+#pragma unroll
+                    for (int j = 0; j < WJ; ++j) {
+                        acc[i][j] = mfma16(wf[ks][j], af[ks][i], acc[i][j]);
+                        constexpr int dummy = 0; (void)dummy;
+                        const int n = (ks * WI + i) * WJ + j + 1;               // MFMAs issued so far (compile-time after unrolling)
+                        if (n % PER == 0 && n / PER <= P) {
+                            const int pc = n / PER - 1;
+                            __builtin_amdgcn_global_load_lds((gptr_t)(src[pc] + k0), (lptr_t)(sn + (pc * NT + wave * 64) * 8), 16, 0, 0);
+                        }
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x100, (WI + WJ) * KS, 0);             // DS reads
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                    // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                      // VMEM read (LDS-DMA piece)
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - P * PER, 0);
+        }
+        st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
+        st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
 
     // epilogue (same rounding points as gemm_tile_kernel)
     const bf16x4 z4 = {0, 0, 0, 0};
-    bf16x4 bv[4];
+    bf16x4 bv[WJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+    for (int j = 0; j < WJ; ++j) {
+        const int n = min(n0 + wn * (16 * WJ) + j * 16 + q * 4, g.N - 4);
         bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r16;
+    for (int i = 0; i < WI; ++i) {
+        const int m = m0 + wm * (16 * WI) + i * 16 + r16;
         const int mc = min(m, g.M - 1);
-        bf16x4 rv[4], pv[4];
+        bf16x4 rv[WJ], pv[WJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
+        for (int j = 0; j < WJ; ++j) {
+            const int n = min(n0 + wn * (16 * WJ) + j * 16 + q * 4, g.N - 4);
             rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
             pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
         }
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + q * 4;
+        for (int j = 0; j < WJ; ++j) {
+            const int n = n0 + wn * (16 * WJ) + j * 16 + q * 4;
             if (n >= g.N) continue;
             bf16x4 o;
 #pragma unroll
@@ -305,31 +356,81 @@ __global__ __launch_bounds__(512, 2) void gemm_tile_dma_kernel(GemmTileArgs g) {
     }
 }
 
-static int g_tile_dma = 1;       // tuning: 0 disables the LDS-DMA variant, 2 forces it whenever the shape allows (tests)
+// tuning "tile_dma": 0 disables the LDS-DMA family, 1 auto, >= 2 forces variant id (tests, sweeps) whenever K allows
+static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
 
-extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
-    if (g->M <= 0 || g->N <= 0) return hipSuccess;
+template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES, bool ILV = false>
+static hipError_t launch_dma(const GemmTileArgs* g, hipStream_t st) {
+    constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
+    constexpr int lds_bytes = STAGES * (BM + BN) * TBK * 2;
+    static_assert(lds_bytes <= 160 * 1024, "stage ring exceeds the CU's LDS");
+    static bool attr_set = false;
+    auto kern = gemm_tile_dma_kernel<WI, WJ, WAVES_M, WAVES_N, STAGES, ILV>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nblk = ceil_div(g->N, BN) * ceil_div(g->M, BM);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WAVES_M * WAVES_N), lds_bytes, st, *g);
+    return hipGetLastError();
+}
+
+static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t st) {
+    switch (v) {
+        case 2: return launch_dma<4, 4, 4, 2, 3, true>(g, st);   // 256x128, 8 waves, 144 KB (1 per CU), DMA/MFMA interleave
+        case 3: return launch_dma<2, 4, 4, 2, 4>(g, st);     // 128x128, 8 waves, 128 KB (1 per CU)
+        case 4: return launch_dma<2, 2, 2, 2, 4>(g, st);     //  64x64,  4 waves,  64 KB (2 per CU)
+        case 5: return launch_dma<2, 2, 2, 2, 3>(g, st);     //  64x64,  4 waves,  48 KB (3 per CU)
+        case 6: return launch_dma<4, 4, 4, 2, 3, false>(g, st);  // 256x128 with the DMA pieces bunched after the barrier (3-8 % slower)
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static hipError_t check_tile_args(const GemmTileArgs* g) {
     if ((long)g->M * g->lda >= (1L << 31) || (long)g->N * g->ldw >= (1L << 31)) return hipErrorInvalidValue;
     if ((g->K & 7) || (g->lda & 7) || (g->ldw & 7) || (g->N & 3) || (g->ldc & 3) || (g->residual && (g->ldr & 3)) ||
         (g->rowadd && (g->ldra & 3)))
         return hipErrorInvalidValue;
+    return hipSuccess;
+}
+
+extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
+    if (g->M <= 0 || g->N <= 0) return hipSuccess;
+    if (hipError_t e = check_tile_args(g); e != hipSuccess) return e;
     const int nblk128 = ceil_div(g->N, 128) * ceil_div(g->M, 128);
-    const int nblk_dma = ceil_div(g->N, DBN) * ceil_div(g->M, DBM);
-    if (g_tile_dma && (g->K % TBK) == 0 && g->K >= 2 * TBK && (nblk_dma >= 256 || g_tile_dma == 2)) {
-        static bool attr_set = false;
-        constexpr int lds_bytes = DSTAGES * (DBM + DBN) * TBK * 2;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(gemm_tile_dma_kernel, dim3(nblk_dma), dim3(512), lds_bytes, st, *g);
-    } else if (nblk128 >= 384) {     // enough 128x128 tiles to fill 256 CUs at 2 workgroups each
+    if (g_tile_dma && (g->K % TBK) == 0 && g->K >= 2 * TBK) {
+        // Measured per shape (tools/diag/gemm_tile_sweep.py, M = 576 ... 18432 x the tower's four GEMM shapes): a CU
+        // ingests ~55 GB/s by LDS-DMA whatever the tile or stage depth (8 stages were no faster than 3), so small
+        // grids go to the variant with the most resident workgroups per CU (64x64, 3 per CU).  The 256x128 tile
+        // (one per CU) wins when its grid fills most of its last round of 256 CUs, except on the thin N = K = 1024 GEMM.
+        const int nblk_l = ceil_div(g->N, 128) * ceil_div(g->M, 256);
+        const float util = (float)nblk_l / (256.f * ceil_div(nblk_l, 256));
+        int v = g_tile_dma;
+        if (v == 1) v = ((util >= 0.6f || (g->K >= 2048 && util >= 0.5f)) && (g->N > 1024 || g->K > 1024)) ? 2 : 5;
+        return launch_dma_variant(v, g, st);
+    }
+    if (nblk128 >= 384) {            // enough 128x128 tiles to fill 256 CUs at 2 workgroups each
         hipLaunchKernelGGL((gemm_tile_kernel<4>), dim3(nblk128), dim3(256), 0, st, *g);
     } else {
         const int nblk64 = ceil_div(g->N, 64) * ceil_div(g->M, 64);
         hipLaunchKernelGGL((gemm_tile_kernel<2>), dim3(nblk64), dim3(256), 0, st, *g);
     }
     return hipGetLastError();
+}
+
+// Developer hook (not part of include/aha_amd.h; used by tools/diag/gemm_tile_sweep.py): one plain GEMM
+// C[M,N] = bf16(A[M,K] W[N,K]^T) with a forced kernel variant (0 = register-staged, >= 2 = LDS-DMA variant id).
+extern "C" int aha_dev_gemm_tile(const void* A, const void* W, void* C, int M, int N, int K, int variant, void* st) {
+    GemmTileArgs g{};
+    g.A = (const bf16*)A; g.lda = K; g.M = M;
+    g.W = (const bf16*)W; g.ldw = K; g.N = N;
+    g.K = K; g.C = (bf16*)C; g.ldc = N;
+    if (check_tile_args(&g) != hipSuccess || (variant >= 2 && (K % TBK || K < 2 * TBK))) return -22;
+    const int saved = g_tile_dma;
+    g_tile_dma = variant;
+    hipError_t e = aha_gemm_tile(&g, (hipStream_t)st);
+    g_tile_dma = saved;
+    return e == hipSuccess ? 0 : -5;
 }

@@ -44,7 +44,28 @@ def parse():
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--vit-cus", type=int, default=0,
+                   help="experiment: restrict the vision stream to this many CUs (HIP CU mask, XCD-balanced)")
+    p.add_argument("--lm-cus", type=int, default=-1,
+                   help="with --vit-cus: CUs of the LM stream (-1 = the complement of the vision stream's, 0 = all)")
     return p.parse_args()
+
+
+def cu_masked_stream(first_cu, n_cus, total_cus):
+    """A HIP stream whose kernels may only run on CUs [first_cu, first_cu+n_cus).  The driver deals consecutive
+    mask bits round-robin over the XCDs, so a contiguous range takes the same share of every XCD."""
+    import ctypes
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)   # the runtime torch loaded
+    hip = ctypes.CDLL(path)
+    words = (total_cus + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for c in range(first_cu, first_cu + n_cus):
+        mask[c // 32] |= 1 << (c % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(st.value)
 
 
 def pmc_traffic(kernel_prefix):
@@ -161,6 +182,12 @@ def main():
     # timed region; --no-overlap serialises them on one stream.
     main_stream = torch.cuda.Stream(priority=-1) if a.lm_priority else torch.cuda.current_stream()   # LM chain: short kernels
     vit_stream = torch.cuda.Stream() if not a.no_overlap else main_stream
+    if a.vit_cus > 0 and not a.no_overlap:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        vit_stream = cu_masked_stream(0, a.vit_cus, n_cu)
+        if a.lm_cus != 0:
+            lm_n = n_cu - a.vit_cus if a.lm_cus < 0 else a.lm_cus
+            main_stream = cu_masked_stream(n_cu - lm_n, lm_n, n_cu)
     emb_buf = [torch.empty((B * F * tf, H), dtype=torch.bfloat16, device=dev) for _ in range(2)]
     emb_ready = [torch.cuda.Event() for _ in range(2)]
     emb_free = [torch.cuda.Event() for _ in range(2)]
