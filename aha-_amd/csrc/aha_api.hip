@@ -52,6 +52,8 @@ struct aha_ctx {
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
+    struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0; };
+    std::map<std::tuple<int, int, int>, IngestTab> ingest_tabs;      // (method, h, w) -> device coefficient tables
     // LM workspaces
     bf16 *h = nullptr, *xn = nullptr, *q_rot = nullptr, *attn_out = nullptr, *act = nullptr;
     float *partial = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *heads_tmp = nullptr;
@@ -593,6 +595,64 @@ static int vit_check(aha_ctx* c, const void* frames, const void* out, int n) {
     if (!c || !frames || !out) return AHA_E_INVAL;
     if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
     if (n > c->d.max_vit_frames) return fail(c, AHA_E_RANGE, "n_frames > max_vit_frames");
+    return 0;
+}
+
+// ---- frame ingest (ingest.hip) -------------------------------------------------------------------------------
+void aha_ingest_pil_tables(int in_size, int out_size, int* ksize_out, std::vector<int>* bounds, std::vector<int>* kk);
+void aha_ingest_cv_tables(int src_size, int dst_size, bool horizontal, std::vector<int>* tab);
+
+static int upload_ints(aha_ctx* c, const std::vector<int>& v, int** dst) {
+    int rc = dalloc(c, dst, v.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));   // once per geometry
+    return 0;
+}
+
+extern "C" int aha_frame_ingest(aha_ctx* c, const uint8_t* src, int height, int width, int src_is_bgr, int method,
+                                uint8_t* out, aha_hip_stream st_) {
+    if (!c) return AHA_E_INVAL;
+    if (!src || !out) return fail(c, AHA_E_INVAL, "null frame pointer");
+    if (method != AHA_RESIZE_PIL_BICUBIC && method != AHA_RESIZE_CV2_LINEAR) return fail(c, AHA_E_INVAL, "unknown resize method");
+    if (height <= 0 || width <= 0 || height > 16384 || width > 16384) return fail(c, AHA_E_RANGE, "frame size out of range");
+    const int S = c->d.image_size;
+    // test/live_infer_for_video.py:108-119: the long side becomes S, the short side int((short / long) * S) in double
+    int new_w, new_h;
+    if (width > height) { new_w = S; new_h = (int)(((double)height / (double)width) * S); }
+    else { new_h = S; new_w = (int)(((double)width / (double)height) * S); }
+    if (new_w < 1 || new_h < 1) return fail(c, AHA_E_RANGE, "aspect ratio leaves an empty resized frame");
+    auto key = std::make_tuple(method, height, width);
+    auto it = c->ingest_tabs.find(key);
+    if (it == c->ingest_tabs.end()) {
+        aha_ctx::IngestTab t;
+        int rc;
+        if (method == AHA_RESIZE_PIL_BICUBIC) {
+            std::vector<int> b, k;
+            if (new_w != width) {
+                aha_ingest_pil_tables(width, new_w, &t.xks, &b, &k);
+                if ((rc = upload_ints(c, b, &t.xb)) || (rc = upload_ints(c, k, &t.xk))) return rc;
+            }
+            if (new_h != height) {
+                aha_ingest_pil_tables(height, new_h, &t.yks, &b, &k);
+                if ((rc = upload_ints(c, b, &t.yb)) || (rc = upload_ints(c, k, &t.yk))) return rc;
+            }
+        } else if (new_w != width || new_h != height) {
+            std::vector<int> tab;
+            aha_ingest_cv_tables(width, new_w, true, &tab);
+            if ((rc = upload_ints(c, tab, &t.xb))) return rc;
+            aha_ingest_cv_tables(height, new_h, false, &tab);
+            if ((rc = upload_ints(c, tab, &t.yb))) return rc;
+        }
+        it = c->ingest_tabs.emplace(key, t).first;
+    }
+    const aha_ctx::IngestTab& t = it->second;
+    IngestArgs a{};
+    a.src = src; a.h = height; a.w = width; a.src_bgr = src_is_bgr ? 1 : 0;
+    a.out = out; a.S = S;
+    a.new_w = new_w; a.new_h = new_h; a.left = (S - new_w) / 2; a.top = (S - new_h) / 2;
+    a.need_h = new_w != width; a.need_v = new_h != height;
+    a.xb = t.xb; a.xk = t.xk; a.xks = t.xks; a.yb = t.yb; a.yk = t.yk; a.yks = t.yks;
+    HIPCHK(c, aha_ingest_launch(&a, method, (hipStream_t)st_));
     return 0;
 }
 

@@ -53,6 +53,16 @@ struct ResidNormArgs {
     int H; float eps;
 };
 
+// frame ingest (ingest.hip): one source frame -> one [3,S,S] canvas
+struct IngestArgs {
+    const uint8_t* src; int h, w, src_bgr;       // uint8 [h][w][3]; src_bgr: channels arrive B,G,R
+    uint8_t* out; int S;                          // uint8 [3][S][S] RGB
+    int new_w, new_h, left, top;                  // resized size and its offset inside the canvas
+    int need_h, need_v;                           // width / height actually change
+    const int* xb; const int* xk; int xks;        // Pillow: bounds [new_w][2], coeffs [new_w][xks];  OpenCV: xb = [new_w][4]
+    const int* yb; const int* yk; int yks;        //         bounds [new_h][2], coeffs [new_h][yks];          yb = [new_h][4]
+};
+
 struct QkvFinishArgs {
     const float* partial; int S; long slab_stride; int ldp;
     const bf16* qkv_bf16; int ldq_in;            // alternative input (bias already added)
@@ -80,4 +90,5 @@ hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, b
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st);
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);
+hipError_t aha_ingest_launch(const IngestArgs* a, int method, hipStream_t st);
 }

@@ -21,6 +21,7 @@ import math
 from dataclasses import asdict
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from .arguments import LiveTestArguments
@@ -327,20 +328,36 @@ class LiveInferForBenchmark:
         return sorted(model_response_list, key=lambda x: x["time"])
 
 
-def pad_to_square(frame_u8: torch.Tensor, output_resolution: int) -> torch.Tensor:
-    """Aspect-preserving resize + centred zero pad of one uint8 [3,h,w] frame, the geometry of
-    load_video / load_one_frame (test/live_infer_for_video.py:49-71,108-121)."""
-    _, h, w = frame_u8.shape
-    if w > h:
-        new_w, new_h = output_resolution, int((h / w) * output_resolution)
-    else:
-        new_h, new_w = output_resolution, int((w / h) * output_resolution)
-    x = torch.nn.functional.interpolate(frame_u8[None].float(), size=(new_h, new_w), mode="bilinear", align_corners=False)
-    x = x.round().clamp(0, 255).to(torch.uint8)[0]
-    top, left = (output_resolution - new_h) // 2, (output_resolution - new_w) // 2
-    canvas = torch.zeros((3, output_resolution, output_resolution), dtype=torch.uint8, device=frame_u8.device)
-    canvas[:, top:top + new_h, left:left + new_w] = x
-    return canvas
+def sample_frame_indices(input_fps, frame_count, output_fps, max_num_frames=None, floor_total=False):
+    """Which decoded frames the reference's loaders keep (load_video_for_testing, test/inference.py:509-571;
+    floor_total=True: load_video, test/live_infer_for_video.py:42-43,74-75).  Decoding itself (cv2.VideoCapture) is
+    outside this package: feed the kept frames to `frames_to_canvases`.  Returns (indices, output_fps, duration)."""
+    video_duration = frame_count / input_fps
+    output_fps = output_fps if output_fps > 0 else max_num_frames / video_duration
+    total = math.floor(video_duration * output_fps) if floor_total else math.ceil(video_duration * output_fps)
+    frame_sec = [i / output_fps for i in range(total)]
+    keep, cur_time, frame_index = [], 0, 0
+    for true_index in range(int(frame_count)):
+        if frame_index < len(frame_sec) and cur_time >= frame_sec[frame_index]:
+            keep.append(true_index)
+            frame_index += 1
+        if max_num_frames and len(keep) >= max_num_frames:
+            break
+        cur_time += 1 / input_fps
+    return keep, output_fps, video_duration
+
+
+def frames_to_canvases(rt, frames_hwc_u8, *, bgr=True, method=None) -> torch.Tensor:
+    """Decoded frames (uint8 [h,w,3] tensors / arrays, B,G,R as cv2 delivers them unless bgr=False) -> uint8
+    [N,3,S,S] on the device, what `input_video_stream` takes: the resize + pad + BGR2RGB + CHW body of
+    load_video_for_testing (test/inference.py:538-562) run by aha_frame_ingest on the GPU."""
+    method = rt.RESIZE_CV2_LINEAR if method is None else method
+    S = rt.cfg.vision.image_size
+    out = torch.empty((len(frames_hwc_u8), 3, S, S), dtype=torch.uint8, device=rt.device)
+    for i, f in enumerate(frames_hwc_u8):
+        f = f if torch.is_tensor(f) else torch.from_numpy(np.ascontiguousarray(f))
+        rt.frame_ingest(f.to(rt.device, non_blocking=True), bgr=bgr, method=method, out=out[i])
+    return out
 
 
 class LiveInferForDemo(LiveInferForBenchmark):
@@ -351,16 +368,16 @@ class LiveInferForDemo(LiveInferForBenchmark):
 
     # ---- test/live_infer_for_video.py:98-128 -----------------------------------------------------------
     def load_one_frame(self, frame_path=None, frame_object=None):
-        """frame_object: uint8 tensor [3,h,w] (or a PIL image / HxWx3 array); frame_path: an image file
-        (needs PIL).  Resize + pad to frame_resolution, encode ONE frame, queue its embedding."""
+        """frame_object: a PIL image / uint8 HxWx3 RGB array or tensor; frame_path: an image file (decoded with PIL).
+        PIL-bicubic resize + centred pad to frame_resolution on the GPU (aha_frame_ingest, bit-exact with the
+        reference's Image.resize + ImageOps.expand), encode ONE frame, queue its embedding."""
         assert frame_path is not None or frame_object is not None
         if frame_object is None:
             from PIL import Image            # optional dependency, only for file input
-            frame_object = Image.open(frame_path)
+            frame_object = Image.open(frame_path).convert("RGB")
         if not torch.is_tensor(frame_object):
-            import numpy as np
-            frame_object = torch.from_numpy(np.array(frame_object)).permute(2, 0, 1)
-        canvas = pad_to_square(frame_object.to(self.device), self.frame_resolution)
+            frame_object = torch.from_numpy(np.ascontiguousarray(np.array(frame_object)))
+        canvas = self.rt.frame_ingest(frame_object.to(self.device), bgr=False, method=self.rt.RESIZE_PIL_BICUBIC)
         frame_embeds = self.rt.visual_embed(canvas[None]).split(self.frame_num_tokens)
         self.frame_embeds_queue.append((self.video_time, frame_embeds[0]))
 

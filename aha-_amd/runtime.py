@@ -199,6 +199,25 @@ class Runtime:
                                               out[i * self.frame_num_tokens:].data_ptr(), _cur_stream()))
         return out
 
+    RESIZE_PIL_BICUBIC, RESIZE_CV2_LINEAR = 0, 1
+
+    def frame_ingest(self, frame_hwc_u8: torch.Tensor, *, bgr: bool = False, method: int = 0,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One decoded frame, uint8 [h,w,3] on device (B,G,R order when `bgr`) -> uint8 [3,S,S] RGB canvas:
+        aspect-preserving resize + centred zero pad, bit-exact with the reference's resampler for that path
+        (method RESIZE_PIL_BICUBIC: load_one_frame, test/live_infer_for_video.py:98-121; RESIZE_CV2_LINEAR:
+        load_video_for_testing, test/inference.py:538-562)."""
+        assert frame_hwc_u8.dtype == torch.uint8 and frame_hwc_u8.is_cuda and frame_hwc_u8.dim() == 3 and frame_hwc_u8.shape[2] == 3
+        frame_hwc_u8 = frame_hwc_u8.contiguous()
+        S = self.cfg.vision.image_size
+        if out is None:
+            out = torch.empty((3, S, S), dtype=torch.uint8, device=self.device)
+        assert out.is_contiguous() and out.shape == (3, S, S) and out.dtype == torch.uint8
+        h, w, _ = frame_hwc_u8.shape
+        self._chk(self.lib.aha_frame_ingest(self.ctx, frame_hwc_u8.data_ptr(), h, w, int(bool(bgr)), int(method),
+                                            out.data_ptr(), _cur_stream()))
+        return out
+
     def vision_live_embed(self, frames_u8: torch.Tensor, pooled: int = 7) -> torch.Tensor:
         """models/vision_live.py:11-31 contract + connector: tower -> post_layernorm -> adaptive average pool to
         pooled x pooled -> mm_projector.  uint8 [N,3,S,S] -> bf16 [N*pooled*pooled, H]."""

@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--tile-dma", type=int, default=-1, help="experiment: force a tiled-GEMM variant in the vision tower")
     p.add_argument("--vit-cus", type=int, default=0,
                    help="experiment: restrict the vision stream to this many CUs (HIP CU mask, XCD-balanced)")
     p.add_argument("--lm-cus", type=int, default=-1,
@@ -155,6 +156,8 @@ def main():
     w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=True)
     rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max(B * (tf + n_sys), 256), max_vit_frames=min(32, B * F),
                  max_positions=cfg.lm.max_position_embeddings)
+    if a.tile_dma >= 0:
+        rt.set_tuning("tile_dma", a.tile_dma)
     want_cpu = (not a.no_cpu_baseline) and rank == 0 and world == 1
     w_cpu = {k: v.cpu() for k, v in w.items()} if want_cpu else None
     del w

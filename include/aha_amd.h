@@ -93,6 +93,19 @@ int aha_vit_encode_pooled_first(aha_ctx* ctx, const uint8_t* frames_u8, int n_fr
 /* parity-test tap: copy the tower output of the last encode, bf16 [n_frames*Np][v_hidden] */
 int aha_vit_last_tower_output(aha_ctx* ctx, int n_frames, void* out, aha_hip_stream st);
 
+/* ---- frame ingest: what the reference does to a decoded frame before preprocess -- aspect-preserving resize to
+ * image_size on the long side, centred zero pad to image_size x image_size, RGB, CHW.  Integer arithmetic, bit-exact.
+ *   AHA_RESIZE_PIL_BICUBIC : PIL Image.resize((w,h)) default resample + ImageOps.expand, as
+ *                            LiveInferForDemo.load_one_frame does (test/live_infer_for_video.py:98-121)
+ *   AHA_RESIZE_CV2_LINEAR  : cv2.resize default INTER_LINEAR + copyMakeBorder(BORDER_CONSTANT 0) + BGR2RGB, the
+ *                            per-frame body of load_video_for_testing / load_video (test/inference.py:538-562,
+ *                            test/live_infer_for_video.py:49-71)
+ * src_hwc_u8: uint8 [height][width][3] on the device, channel order B,G,R when src_is_bgr (cv2 decode) else R,G,B;
+ * out_canvas_u8: uint8 [3][image_size][image_size], ready for aha_vit_encode. */
+enum { AHA_RESIZE_PIL_BICUBIC = 0, AHA_RESIZE_CV2_LINEAR = 1 };
+int aha_frame_ingest(aha_ctx* ctx, const uint8_t* src_hwc_u8, int height, int width, int src_is_bgr, int method,
+                     uint8_t* out_canvas_u8, aha_hip_stream st);
+
 /* model.get_input_embeddings()(ids) (test/inference.py:212) */
 int aha_embed_tokens(aha_ctx* ctx, const int64_t* ids_dev, int n, void* out_embeds, aha_hip_stream st);
 

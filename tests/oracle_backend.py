@@ -3,6 +3,7 @@ host logic of the drivers (queues, prompts, trigger rules, rounding, sharding) c
 without a GPU.  Lives under tests/ - the product never imports it."""
 import torch
 
+from oracle import frame_ingest as oracle_ingest
 from oracle.cache_policies import make_policy
 from oracle.qwen2_live import OracleLM, frame_scores
 from oracle.vision_tower import OracleVision
@@ -33,6 +34,21 @@ class OracleBackedRuntime:
 
     def open_stream(self, alt_cache="default_sink", window_length=2048, num_sink_tokens=32, capacity=None, attn_semantics="trailing"):
         return _FakeStream(alt_cache, window_length, num_sink_tokens)
+
+    RESIZE_PIL_BICUBIC, RESIZE_CV2_LINEAR = 0, 1
+
+    def frame_ingest(self, frame_hwc_u8, *, bgr=False, method=0, out=None):
+        f = frame_hwc_u8.cpu().numpy()
+        S = self.cfg.vision.image_size
+        if method == self.RESIZE_PIL_BICUBIC:
+            canvas = oracle_ingest.demo_frame_to_canvas(f[:, :, ::-1] if bgr else f, S)
+        else:
+            canvas = oracle_ingest.benchmark_frame_to_canvas(f if bgr else f[:, :, ::-1], S)
+        canvas = torch.from_numpy(canvas.copy())
+        if out is not None:
+            out.copy_(canvas)
+            return out
+        return canvas
 
     def visual_embed(self, frames_u8):
         return self.vis.visual_embed(frames_u8)

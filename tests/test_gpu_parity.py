@@ -527,3 +527,72 @@ def test_vision_live_contract_pooled_first():
     assert got.shape == want.shape == (2 * 49, 256)
     assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
     rt.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# frame ingest (integer path: bit-exact)
+# ---------------------------------------------------------------------------------------------------
+def test_frame_ingest_matches_pillow_golden_vectors(tiny, tiny128):
+    """aha_frame_ingest (PIL-bicubic method) against canvases produced by Pillow's own Image.resize + ImageOps.expand
+    (tests/golden/frame_ingest.npz, generated by tools/make_golden.py): exact."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from make_golden import INGEST_CASES, ingest_frame
+    gold = np.load(os.path.join(root, "tests", "golden", "frame_ingest.npz"))
+    rts = {56: tiny[2], 84: tiny128[2]}
+    for i, (S, h, w) in enumerate(INGEST_CASES):
+        rt = rts[S]
+        got = rt.frame_ingest(torch.from_numpy(ingest_frame(i, h, w)).cuda(), method=rt.RESIZE_PIL_BICUBIC).cpu().numpy()
+        assert np.array_equal(got, gold[f"canvas_{i}"]), (i, S, h, w)
+
+
+def test_frame_ingest_full_size_both_methods_bit_exact(bench_rt):
+    """720p / 1080p / portrait / upscaled / same-size frames at the benchmark resolution: both resamplers equal the
+    oracle exactly (Pillow restatement pinned in tests/test_frame_ingest.py; the OpenCV one is the published
+    algorithm), channel order handled, padding zero, and a frame ingested on the GPU encodes like its canvas."""
+    from oracle import frame_ingest as fi
+    from aha_amd.runtime import AhaError
+    cfg, rt = bench_rt
+    S = cfg.vision.image_size
+    rng = np.random.default_rng(11)
+    for h, w in [(720, 1280), (1280, 720), (1080, 1920), (100, 60), (S, S), (S + 1, S - 1), (2, 5)]:
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        dev = torch.from_numpy(rgb).cuda()
+        want_pil = fi.demo_frame_to_canvas(rgb, S)
+        got = rt.frame_ingest(dev, bgr=False, method=rt.RESIZE_PIL_BICUBIC).cpu().numpy()
+        assert np.array_equal(got, want_pil), ("pil", h, w, int(np.abs(got.astype(int) - want_pil.astype(int)).max()))
+        want_cv = fi.benchmark_frame_to_canvas(rgb, S)                     # rgb interpreted as a B,G,R frame
+        got = rt.frame_ingest(dev, bgr=True, method=rt.RESIZE_CV2_LINEAR).cpu().numpy()
+        assert np.array_equal(got, want_cv), ("cv2", h, w, int(np.abs(got.astype(int) - want_cv.astype(int)).max()))
+        # channel flag: the same bytes read as BGR give the RGB result with planes 0 and 2 exchanged
+        got_bgr = rt.frame_ingest(dev, bgr=True, method=rt.RESIZE_PIL_BICUBIC).cpu().numpy()
+        assert np.array_equal(got_bgr, want_pil[::-1])
+    canvas = rt.frame_ingest(dev, method=rt.RESIZE_PIL_BICUBIC)
+    assert torch.equal(rt.visual_embed(canvas[None]), rt.visual_embed(torch.from_numpy(want_pil).cuda()[None]))
+    with pytest.raises(AhaError):
+        rt._chk(rt.lib.aha_frame_ingest(rt.ctx, dev.data_ptr(), 2, 5, 0, 7, canvas.data_ptr(), None))     # unknown method
+    with pytest.raises(AhaError):
+        rt._chk(rt.lib.aha_frame_ingest(rt.ctx, dev.data_ptr(), 1, 5000, 0, 0, canvas.data_ptr(), None))  # resized height 0
+
+
+def test_demo_driver_ingests_arbitrary_frames_on_gpu(tiny):
+    """LiveInferForDemo.load_one_frame on a non-square frame: GPU ingest + encode + step equals the oracle-backed
+    driver fed the same frame (resize by the oracle's Pillow restatement)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_backend import OracleBackedRuntime
+    from aha_amd.arguments import LiveTestArguments
+    from aha_amd.live_infer import LiveInferForDemo
+    cfg, w, rt = tiny
+    frame = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (45, 80, 3), dtype=np.uint8))
+    args = LiveTestArguments(stream_end_prob_threshold=9.0, frame_fps=1)
+    outs = []
+    for runtime in (rt, OracleBackedRuntime(cfg, {k: v.cpu() for k, v in w.items()}, torch.bfloat16)):
+        demo = LiveInferForDemo(args, runtime=runtime)
+        demo.load_one_frame(frame_object=frame)
+        outs.append(demo.input_one_frame())
+    for k in ("informative_score", "relevance_score"):
+        assert abs(outs[0][k] - outs[1][k]) <= SCORE_TOL, (k, outs)

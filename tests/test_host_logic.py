@@ -10,7 +10,8 @@ import torch
 import aha_amd  # noqa: F401
 from aha_amd.arguments import LiveTestArguments
 from aha_amd.config import preset
-from aha_amd.live_infer import LiveInferForBenchmark, LiveInferForDemo, pad_to_square, round_numbers
+from aha_amd.live_infer import (LiveInferForBenchmark, LiveInferForDemo, frames_to_canvases, round_numbers,
+                                sample_frame_indices)
 from aha_amd.synth import make_frames, make_weights
 from aha_amd.tokenization import SyntheticChatTokenizer
 from oracle.live_driver import OracleLiveInfer, round_numbers as oracle_round
@@ -108,14 +109,27 @@ def test_find_ticks_and_demo_frame_geometry():
     scores = 0.2 + 0.5 * np.exp(-0.5 * ((t - 30) / 3.0) ** 2) + 0.4 * np.exp(-0.5 * ((t - 85) / 4.0) ** 2)
     assert demo.find_ticks(scores, fps=1) == [30.0, 85.0]
     assert demo.find_ticks(list(scores), fps=2) == [15.0, 42.5]
-    f = torch.full((3, 20, 40), 200, dtype=torch.uint8)                 # landscape: height padded
-    sq = pad_to_square(f, cfg.frame_resolution)
+    f = torch.full((20, 40, 3), 200, dtype=torch.uint8)                 # landscape HWC frame: height padded
     S = cfg.frame_resolution
-    assert sq.shape == (3, S, S) and sq[:, 0].max() == 0 and sq[:, S // 2].min() == 200
+    sq = frames_to_canvases(demo.rt, [f, f.numpy()], bgr=True)
+    assert sq.shape == (2, 3, S, S) and sq[:, :, 0].max() == 0 and sq[:, :, S // 2].min() == 200
     demo.load_one_frame(frame_object=f)
     out = demo.input_one_frame()
     assert set(out) == {"frame_idx", "time", "uncertainty_score", "informative_score", "relevance_score", "response"}
     assert out["frame_idx"] == 1 and out["response"] is None
+
+
+def test_sample_frame_indices_follows_the_reference_clock():
+    """the frame-keeping rule of load_video_for_testing / load_video (running float clock vs i/output_fps)"""
+    from oracle.frame_ingest import sample_frame_indices as oracle_sample
+    for fps_in, count, fps_out, cap, floor_total in [(30.0, 300, 2, None, False), (29.97, 451, 2, None, False),
+                                                    (25.0, 1000, 1, 7, False), (30.0, 95, 0, 12, False),
+                                                    (24.0, 240, 2, 400, True), (59.94, 600, 0.5, None, True)]:
+        got = sample_frame_indices(fps_in, count, fps_out, cap, floor_total)
+        assert got == oracle_sample(fps_in, count, fps_out, cap, floor_total)
+    keep, out_fps, dur = sample_frame_indices(30.0, 300, 2)
+    # the clock is a float accumulated 1/30 per decoded frame: after 15 frames it is 0.49999..., so frame 16 is kept
+    assert keep[:4] == [0, 16, 31, 45] and len(keep) == 20 and out_fps == 2 and dur == 10.0
 
 
 # ---- multi-process: stream sharding + score all-gather over gloo, world_size 2 -----------------------

@@ -11,6 +11,8 @@ Fixtures are data (seeds, inputs, expected outputs), never reference source text
   qwen2_tiny_steps.npz last_hidden_state of local transformers Qwen2Model + DynamicCache
                        (fp32, sdpa) on the 'tiny' preset with aha_amd.synth weights.
   siglip_tiny.npz      hidden_states[-1] of local transformers SiglipVisionModel (fp32).
+  frame_ingest.npz     canvases produced by Pillow itself (Image.resize default BICUBIC + ImageOps.expand, the
+                       calls of LiveInferForDemo.load_one_frame) for seeded uint8 frames at S = 56 / 84.
 """
 import os
 import sys
@@ -154,8 +156,30 @@ def gen_postproc():
     print("postproc.json", out)
 
 
+INGEST_CASES = [(56, 40, 72), (56, 72, 40), (56, 56, 56), (56, 23, 31), (56, 113, 200), (84, 150, 97), (84, 84, 60), (84, 9, 200)]
+
+
+def ingest_frame(i, h, w):
+    return np.random.default_rng(7000 + i).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def gen_frame_ingest():
+    """expected = what the reference's own calls produce, run with the Pillow installed here"""
+    from PIL import Image, ImageOps
+    from oracle.frame_ingest import resize_geometry
+    out = {}
+    for i, (S, h, w) in enumerate(INGEST_CASES):
+        img = ingest_frame(i, h, w)
+        new_w, new_h, border = resize_geometry(w, h, S)
+        canvas = ImageOps.expand(Image.fromarray(img).resize((new_w, new_h)), border=border, fill=(0, 0, 0))
+        out[f"canvas_{i}"] = np.ascontiguousarray(np.array(canvas).transpose(2, 0, 1))
+    np.savez_compressed(os.path.join(OUT, "frame_ingest.npz"), **out)
+    print("frame_ingest.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_frame_ingest()
     gen_postproc()
     gen_cache()
     gen_qwen2()
