@@ -357,6 +357,159 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tile_dma_kernel(G
 }
 
 // ---------------------------------------------------------------------------------------------
+// 32-deep k-stages: the same LDS-DMA structure with BK = 32, so a 256x128 stage is 24 KB and three of them (72 KB)
+// let TWO workgroups share a CU (<= 128 VGPRs each): while one workgroup's waves are parked on their vmcnt/barrier
+// (39-47 % of wave cycles in the 64-deep kernel, profiles/r01_pmc_mfma_vit32.json) the other one computes.
+// LDS image: 64-byte rows (4 chunks), chunk index XOR (row >> 2) & 3: the 16 rows a ds_read_b128 group touches span
+// four 256-byte bank rows and get four different 16-byte slots in each - conflict-free.  Same k order: bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_kernel(GemmTileArgs g) {
+    constexpr int BK = 32;
+    constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ, NT = 64 * WAVES_M * WAVES_N;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * BK;
+    constexpr int P = ROWS * 4 / NT;                                // 16-B DMA pieces per thread per stage
+    static_assert(ROWS * 4 % NT == 0, "stage image must split evenly over the threads");
+    static_assert((STAGES - 2) * P <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
+    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles_n = ceil_div(g.N, BN), tiles_m = ceil_div(g.M, BM);
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    constexpr int GROUP_M = BM >= 256 ? 4 : 8;
+    const int per_group = GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gmn = min(tiles_m - first_m, GROUP_M), inner = bid % per_group;
+    const int bm = first_m + inner % gmn, bn = inner / gmn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nk = g.K / BK;
+
+    f32x4 acc[WI][WJ];
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16* src[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int c = i * NT + tid, row = c >> 2, ch = (c & 3) ^ ((row >> 2) & 3);
+        src[i] = row < BM ? g.A + min(m0 + row, g.M - 1) * g.lda + ch * 8
+                          : g.W + min(n0 + row - BM, g.N - 1) * g.ldw + ch * 8;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        const int k0 = min(s, nk - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + k0), (lptr_t)(lds + s * STAGE + (i * NT + wave * 64) * 8), 16, 0, 0);
+    }
+    int st_cur = 0, st_new = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");
+        __builtin_amdgcn_s_barrier();
+        constexpr int NM = WI * WJ, PER = NM / (P + 1);
+        const bf16* sa = lds + st_cur * STAGE;
+        const bf16* sb = sa + BM * BK;
+        bf16* sn = lds + st_new * STAGE;
+        const int k0 = min(kt + STAGES - 1, nk - 1) * BK;
+        bf16x8 af[WI], wf[WJ];
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = wm * (16 * WI) + i * 16 + r16;
+            af[i] = *reinterpret_cast<const bf16x8*>(&sa[row * BK + ((q ^ ((row >> 2) & 3)) << 3)]);
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int wrow = wn * (16 * WJ) + j * 16 + r16;
+            wf[j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * BK + ((q ^ ((wrow >> 2) & 3)) << 3)]);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i)
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                const int n = i * WJ + j + 1;
+                if (n % PER == 0 && n / PER <= P) {
+                    const int pc = n / PER - 1;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src[pc] + k0), (lptr_t)(sn + (pc * NT + wave * 64) * 8), 16, 0, 0);
+                }
+            }
+        __builtin_amdgcn_sched_group_barrier(0x100, WI + WJ, 0);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - P * PER, 0);
+        st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
+        st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int n = min(n0 + wn * (16 * WJ) + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int m = m0 + wm * (16 * WI) + i * 16 + r16;
+        const int mc = min(m, g.M - 1);
+        bf16x4 rv[WJ], pv[WJ];
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int n = min(n0 + wn * (16 * WJ) + j * 16 + q * 4, g.N - 4);
+            rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
+            pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
+        }
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int n = n0 + wn * (16 * WJ) + j * 16 + q * 4;
+            if (n >= g.N) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));
+                if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
+                else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
+                if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
+                o[e] = f2bf(x);
+            }
+            *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
+        }
+    }
+}
+
+template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
+static hipError_t launch_dma32(const GemmTileArgs* g, hipStream_t st) {
+    constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
+    constexpr int lds_bytes = STAGES * (BM + BN) * 32 * 2;
+    static bool attr_set = false;
+    auto kern = gemm_tile_dma32_kernel<WI, WJ, WAVES_M, WAVES_N, STAGES>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nblk = ceil_div(g->N, BN) * ceil_div(g->M, BM);
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WAVES_M * WAVES_N), lds_bytes, st, *g);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // 256x256x64 tile, 8 waves as 2(M) x 4(N), each wave 128x64 = 8x4 accumulator tiles (128 VGPRs).  Half the operand
 // bytes per flop of the 256x128 tile, which is what caps that one (a CU ingests only ~35-55 GB/s by LDS-DMA).
 // A k-tile is staged as four 16 KB half-tiles - A0/A1 = the rows of every wave's upper/lower 64-row half, W0/W1 = the
@@ -577,6 +730,8 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 5: return launch_dma<2, 2, 2, 2, 3>(g, st);     //  64x64,  4 waves,  48 KB (3 per CU)
         case 6: return launch_dma<4, 4, 4, 2, 3, false>(g, st);  // 256x128 with the DMA pieces bunched after the barrier (3-8 % slower)
         case 7: return launch_256(g, st);                        // 256x256, 8 waves, 128 KB, half-tile refills
+        case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
+        case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         default: return hipErrorInvalidValue;
     }
 }
@@ -597,11 +752,19 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
         // Measured per shape (tools/diag/gemm_tile_sweep.py, M = 576 ... 18432 x the tower's four GEMM shapes): a CU
         // ingests ~55 GB/s by LDS-DMA whatever the tile or stage depth (8 stages were no faster than 3), so small
         // grids go to the variant with the most resident workgroups per CU (64x64, 3 per CU).  The 256x128 tile
-        // (one per CU) wins when its grid fills most of its last round of 256 CUs, except on the thin N = K = 1024 GEMM.
+        // (one per CU) wins when its grid fills most of its last round of 256 CUs, except on the thin N = K = 1024 GEMM;
+        // with short K and a large grid the 32-deep variant (two workgroups per CU hide each other's waits) beats it.
         const int nblk_l = ceil_div(g->N, 128) * ceil_div(g->M, 256);
         const float util = (float)nblk_l / (256.f * ceil_div(nblk_l, 256));
         int v = g_tile_dma;
-        if (v == 1) v = ((util >= 0.6f || (g->K >= 2048 && util >= 0.5f)) && (g->N > 1024 || g->K > 1024)) ? 2 : 5;
+        if (v == 10) {                                   // experiment: auto, but 256x256 (fewest operand bytes) on wide large grids
+            const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
+            v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
+        }
+        if (v == 1) {
+            if (g->K < 2048 && nblk_l >= 400) v = 8;     // 32-deep stages, two workgroups per CU: +7-10 % on the K = 1024 GEMMs
+            else v = ((util >= 0.6f || (g->K >= 2048 && util >= 0.5f)) && (g->N > 1024 || g->K > 1024)) ? 2 : 5;
+        }
         return launch_dma_variant(v, g, st);
     }
     if (nblk128 >= 384) {            // enough 128x128 tiles to fill 256 CUs at 2 workgroups each

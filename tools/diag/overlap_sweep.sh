@@ -7,8 +7,8 @@ run() { echo "== $*" | tee -a $out; timeout -k 10 240 python bench.py --no-cpu-b
         | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'])" | tee -a $out; }
 run
 run --no-overlap
+run --tile-dma 10
+run --tile-dma 10 --no-overlap
+run --tile-dma 2
 run --tile-dma 5
-run --tile-dma 5 --no-overlap
-run --tile-dma 4
 run --tile-dma 0
-run --tile-dma 6
