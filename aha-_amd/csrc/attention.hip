@@ -280,6 +280,194 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dense (vision tower) attention: the same S^T = K Q^T / online softmax / O^T += V^T P^T structure per query row as
+// attn_fwd_kernel, without the LM's cache addressing, with the softmax in the base-2 domain (one FMA + one v_exp_f32
+// per probability, mask only in the tail block), and with TPW 16-row query tiles per wave (a workgroup covers 64*TPW
+// rows of one head; TPW > 1 stages 1/TPW of the K/V bytes and shares every V^T fragment read between TPW MFMAs).
+// A row's instruction sequence does not depend on TPW, so all settings are bit-identical; see launch_attn for why
+// TPW = 1 is the default.
+// ---------------------------------------------------------------------------------------------
+template <int D, int TPW>
+__global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int b = blockIdx.z;
+    const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4 * TPW);
+    const int hk = blockIdx.y / RG, rg = blockIdx.y % RG;
+    const int Lk = a.Lk, ldk = a.ldk;
+    const bf16* kb = a.k + b * a.kv_bs + hk * a.hd;
+    const bf16* vb = a.v + b * a.kv_bs + hk * a.hd;
+    const int j1 = Lk;
+    if (j1 <= 0) return;
+
+    const int rt0 = (rg * 4 + wave) * TPW;
+    const bool wave_on = rt0 < RT;
+    bool row_ok[TPW];
+    int trow[TPW], thead[TPW];
+    bf16x8 qf[TPW][C::KSQ];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        int r = (rt0 + tt) * 16 + r16;
+        row_ok[tt] = (rt0 + tt) < RT && r < R;
+        if (r > R - 1) r = R - 1;
+        trow[tt] = r % a.T;
+        thead[tt] = hk * a.G + r / a.T;
+        // channels >= a.hd (zero padding of a head dim that is not a template size) come from a clamped address
+        const bf16* qp = a.q + b * a.q_bs + (long)trow[tt] * a.ldq + thead[tt] * a.hd;
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < C::KSQ; ++ks) {
+            const int d0 = ks * 32 + q4 * 8;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + min(d0, a.hd - 8));
+            qf[tt][ks] = d0 < a.hd ? v : z8;
+        }
+    }
+
+    f32x4 o[TPW][C::DT];
+    float m_run[TPW], l_run[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        m_run[tt] = -INFINITY;
+        l_run[tt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::DT; ++i) o[tt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // K/V staging: issue-early / write-late, two key blocks in flight (see attn_fwd_kernel)
+    constexpr int NCH = (64 * C::CPR) / 256;
+    bf16x8 kA[NCH], vA[NCH], kB[NCH], vB[NCH];
+    auto gload = [&](bf16x8 (&kreg)[NCH], bf16x8 (&vreg)[NCH], int jb) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            int j = jb + row; if (j > j1 - 1) j = j1 - 1;
+            const int dch = min(ch * 8, a.hd - 8);
+            kreg[i] = *reinterpret_cast<const bf16x8*>(kb + (long)j * ldk + dch);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(vb + (long)j * ldk + dch);
+        }
+    };
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int vrow = 4 * q4 + (r16 >> 2), vcol = 4 * (r16 & 3);
+    const float c2 = a.scale * 1.4426950408889634f;                 // scale * log2(e)
+    auto block = [&](bf16x8 (&kreg)[NCH], bf16x8 (&vreg)[NCH], int jb) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C::CPR, ch = idx % C::CPR;
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const bool pad = ch * 8 >= a.hd;
+            const bf16x8 kv = pad ? z8 : kreg[i], vv = pad ? z8 : vreg[i];
+            *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
+            *reinterpret_cast<bf16x8*>(&Vs[row * C::VST + ch * 8]) = vv;
+        }
+        __syncthreads();
+        gload(kreg, vreg, jb + 128);
+        if (!wave_on) return;
+
+        // ---- per tile: online softmax in the base-2 domain.  softmax(scale*s) = 2^(c*s - c*max) / sum with
+        // c = scale*log2(e) > 0, so the running max is kept as c*max(s) and every probability costs one FMA and one
+        // v_exp_f32; keys past the end exist only in the last block, so only that block pays for the mask.
+        // One tile at a time (its 16 score registers die before the next tile starts; the K fragments are re-read from
+        // LDS per tile - LDS has the bandwidth, the register file does not: keeping all tiles' scores live cost 240
+        // AGPR moves per block).
+        bf16x8 pb[TPW][2];
+        const bool tail = jb + 64 > j1;                              // uniform
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int row = kt * 16 + r16;
+#pragma unroll
+                for (int ks = 0; ks < C::KSQ; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (row & (C::CPR - 1))) << 3)]);
+                    s[kt] = mfma16(kf, qf[tt][ks], s[kt]);
+                }
+            }
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (jb + kt * 16 + 4 * q4 + e >= j1) s[kt][e] = -INFINITY;
+            }
+            float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) bmax = fmaxf(bmax, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const float m_new = fmaxf(m_run[tt], bmax * c2);         // -inf * c2 = -inf
+            float alpha = 1.f, psum = 0.f;
+            if (m_new == -INFINITY) {
+                pb[tt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                pb[tt][1] = pb[tt][0];
+            } else {
+                alpha = __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf -> 0
+                const float nm = -m_new;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
+                        psum += p;
+                        pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                    }
+            }
+            m_run[tt] = m_new;
+            l_run[tt] = l_run[tt] * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < C::DT; ++i) o[tt][i] *= alpha;
+            if (TPW > 1) __builtin_amdgcn_sched_barrier(0);          // keep the tiles sequential (hipcc would re-merge them)
+        }
+        // ---- O^T += V^T P^T: one transposed V fragment feeds TPW MFMAs
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[((2 * kp) * 16 + vrow) * C::VST + dt * 16 + vcol]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[((2 * kp + 1) * 16 + vrow) * C::VST + dt * 16 + vcol]));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) o[tt][dt] = mfma16(vf, pb[tt][kp], o[tt][dt]);
+            }
+        }
+    };
+    gload(kA, vA, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    gload(kB, vB, 64);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int jb = 0; jb < j1; jb += 128) {
+        block(kA, vA, jb);
+        block(kB, vB, jb + 64);
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        float l = l_run[tt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[tt]) continue;
+        const float inv = 1.0f / l;
+        bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * a.hd + 4 * q4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 ov = {f2bf(o[tt][dt][0] * inv), f2bf(o[tt][dt][1] * inv), f2bf(o[tt][dt][2] * inv), f2bf(o[tt][dt][3] * inv)};
+            if (dt * 16 + 4 * q4 < a.hd) *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+        }
+    }
+}
+
 // Merge key splits: one block of D threads per (b, kv head, row).
 template <int D>
 __global__ void attn_combine_kernel(AttnArgs a, StepDesc sd) {
@@ -301,6 +489,9 @@ __global__ void attn_combine_kernel(AttnArgs a, StepDesc sd) {
     if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(acc / L);
 }
 
+static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of the dense kernel (0 = auto, 1..3 forced)
+extern "C" void aha_attention_set_dense_tpw(int v) { g_dense_tpw = v; }
+
 template <int D>
 static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipStream_t st) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
@@ -310,9 +501,23 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipS
         if (a.n_splits > 1)
             hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, *sd);
     } else {
-        StepDesc dummy;
-        dummy.B = B; dummy.T = a.T;
-        hipLaunchKernelGGL((attn_fwd_kernel<D, false>), grid, dim3(256), 0, st, a, dummy);
+        // dense (vision tower): one query tile per wave while the grid is small (single-frame latency), more tiles per
+        // wave (less K/V staging per flop) once it fills the chip several times over
+        // Measured on 32 frames (4608 x 10 key blocks): 1 / 2 / 3 tiles per wave give the same tower time within noise
+        // (20.2 / 20.6 / 20.2 ms): the kernel is bound by instruction issue (VALU softmax + exp + LDS fragment reads +
+        // MFMA add up to the measured ~108 us with little overlap), not by K/V staging.  Default: one tile per wave, the
+        // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
+        int tpw = g_dense_tpw == 0 ? 1 : g_dense_tpw;
+        if (D > 64) tpw = 1;
+        if (tpw == 3) {
+            dim3 g(1, a.Hkv * ceil_div(RT, 12), B);
+            hipLaunchKernelGGL((attn_dense_kernel<D, D <= 64 ? 3 : 1>), g, dim3(256), 0, st, a);
+        } else if (tpw == 2) {
+            dim3 g(1, a.Hkv * ceil_div(RT, 8), B);
+            hipLaunchKernelGGL((attn_dense_kernel<D, D <= 64 ? 2 : 1>), g, dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((attn_dense_kernel<D, 1>), grid, dim3(256), 0, st, a);
+        }
     }
     return hipGetLastError();
 }

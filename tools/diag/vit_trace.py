@@ -10,6 +10,7 @@ cfg = preset(sys.argv[4] if len(sys.argv) > 4 else "bench")
 w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
 rt = Runtime(cfg, w, max_step_tokens=64, max_vit_frames=32); del w
 rt.set_tuning("tile_dma", mode)
+if len(sys.argv) > 5: rt.set_tuning("attn_tpw", int(sys.argv[5]))
 fr = make_frames(n, cfg.vision.image_size, seed=0).cuda()
 import time
 for _ in range(2): rt.visual_embed(fr)
