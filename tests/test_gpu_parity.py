@@ -637,3 +637,23 @@ def test_demo_driver_ingests_arbitrary_frames_on_gpu(tiny):
         outs.append(demo.input_one_frame())
     for k in ("informative_score", "relevance_score"):
         assert abs(outs[0][k] - outs[1][k]) <= SCORE_TOL, (k, outs)
+
+
+def test_synthetic_tvsum_eval_path_runs_end_to_end(tmp_path):
+    """BASELINE configs[4] in miniature: tools/eval_synth_tvsum.py (driver API -> prediction JSON -> fused score ->
+    TVSum metrics -> peak picking) on the tiny preset; the records follow the reference's prediction schema."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "synth")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "eval_synth_tvsum.py"), "--preset", "tiny", "--videos", "3",
+                        "--min-frames", "20", "--max-frames", "30", "--out", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["videos"] == 3 and summary["finite"] and 60 <= summary["frames"] <= 90
+    assert set(summary["metrics_on_synthetic_gt"]) == {"mAP50", "mAP15", "top5_mAP", "spearman", "kendall", "f1_15"}
+    recs = json.load(open(os.path.join(out, "predictions.json")))
+    assert len(recs) == 3 and set(recs[0]) == {"video_uuid", "model_response_list", "video_duration", "true_frames_list", "debug_data"}
+    assert set(recs[0]["debug_data"][0]) >= {"time", "informative_score", "relevance_score", "uncertainty_score"}
