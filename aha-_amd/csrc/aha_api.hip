@@ -52,6 +52,8 @@ struct aha_ctx {
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
+    // fused MLP block (lm_fused.hip): device arrival counter + its host-side base, error flag, switch
+    unsigned long long* bar_ctr = nullptr; unsigned long long bar_base = 0; int* bar_err = nullptr; int fuse_mlp = 0, n_cus = 0;
     struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0; };
     std::map<std::tuple<int, int, int>, IngestTab> ingest_tabs;      // (method, h, w) -> device coefficient tables
     // LM workspaces
@@ -158,6 +160,16 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if ((rc = dalloc(c, &c->logits, (size_t)AHA_MAX_B * d->vocab))) return rc;
     if ((rc = dalloc(c, &c->heads_tmp, M * 4))) return rc;
 
+    // ---- fused-kernel barrier state
+    if ((rc = dalloc(c, &c->bar_ctr, 16 * 17)) || (rc = dalloc(c, &c->bar_err, 1))) return rc;
+    if (hipMemset(c->bar_ctr, 0, 16 * 17 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->bar_err, 0, sizeof(int)) != hipSuccess)
+        return fail(c, AHA_E_NOMEM, "hipMemset failed");
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(c, AHA_E_HIP, "hipGetDeviceProperties failed");
+        c->n_cus = prop.multiProcessorCount;
+    }
+
     // ---- ViT workspaces
     const size_t R = (size_t)d->max_vit_frames * c->Np, Dv = d->v_hidden;
     if ((rc = dalloc(c, &c->v_a0, R * c->Kp))) return rc;
@@ -197,6 +209,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
     else if (k == "fuse_static") c->fuse_static = value;
+    else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64)
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);      // 0 off, 1 auto (default), 2 force
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
@@ -721,6 +734,19 @@ static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_
     return S;
 }
 
+static GemmWsArgs ws_args(const bf16* X, int ldx, int M, int m0, int mrows, const PackedW& w, int S, float* partial, int ldp, bf16* out,
+                          int ldo, float* outf, int ldof) {
+    GemmWsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X + (long)m0 * ldx; a.ldx = ldx; a.M = mrows;
+    a.Wp = w.p; a.KS = w.KS; a.Kx = w.K; a.n_tiles = w.n_tiles; a.S = S;
+    a.partial = partial ? partial + (long)m0 * ldp : nullptr; a.ldp = ldp; a.slab_stride = (long)M * ldp;
+    a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
+    a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;
+    a.bias = nullptr; a.N = w.N;
+    return a;
+}
+
 static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
                    bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
     const int mmax = aha_gemm_ws_max_m(epi);
@@ -735,14 +761,7 @@ static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const Pa
         HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].first, st));
     }
     for (int m0 = 0; m0 < M; m0 += mmax) {
-        GemmWsArgs a;
-        memset(&a, 0, sizeof(a));
-        a.X = X + (long)m0 * ldx; a.ldx = ldx; a.M = (M - m0 < mmax) ? M - m0 : mmax;
-        a.Wp = w.p; a.KS = w.KS; a.Kx = w.K; a.n_tiles = w.n_tiles; a.S = S;
-        a.partial = partial ? partial + (long)m0 * ldp : nullptr; a.ldp = ldp; a.slab_stride = (long)M * ldp;
-        a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
-        a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;
-        a.bias = nullptr; a.N = w.N;
+        GemmWsArgs a = ws_args(X, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, w, S, partial, ldp, out, ldo, outf, ldof);
         HIPCHK(c, aha_gemm_ws(&a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
     }
     if (timed) {
@@ -867,19 +886,39 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         memset(&ra, 0, sizeof(ra));
         ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
         ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
-        HIPCHK(c, aha_resid_norm(&ra, M, st));
-        // gate/up with fused SwiGLU epilogue
-        if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
-        // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
         const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
-        if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+        // One launch for resid_norm + gate/up + down (lm_fused.hip) when the step is a single small row block and both GEMM
+        // phases fit one workgroup per CU; otherwise (and while a GEMM kind is being timed) three launches.  c->partial is
+        // shared safely: o_proj's slabs are read in phase A, down's are written in phase C, two grid barriers later.
+        const int gu_blocks = ceil_div(w.gateup.n_tiles, 16), dn_blocks = ceil_div(w.down.n_tiles, 8) * Sd;
+        const bool fuse = c->fuse_mlp && M <= 64 && !c->time_gemm && c->wpb[GK_GATEUP] == 8 && c->wpb[GK_DOWN] == 8 &&
+                          gu_blocks <= c->n_cus && dn_blocks <= c->n_cus && M <= c->n_cus;
+        if (fuse) {
+            MlpBlockArgs mb;
+            memset(&mb, 0, sizeof(mb));
+            mb.rn = ra; mb.M = M;
+            mb.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
+            mb.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
+            mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err;
+            const int grid = c->n_cus < 256 ? c->n_cus : 256;
+            HIPCHK(c, aha_lm_mlp_block(&mb, grid, st));
+            c->bar_base += (unsigned long long)aha_lm_mlp_block_counter_step(grid);
+            c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
+            c->last_flops += 2.0 * 16.0 * M * ((double)w.gateup.n_tiles * w.gateup.K + (double)w.down.n_tiles * w.down.K);
+        } else {
+            HIPCHK(c, aha_resid_norm(&ra, M, st));
+            // gate/up with fused SwiGLU epilogue
+            if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
+            // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
+            if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+        }
         ra.S = Sd;
         ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
         HIPCHK(c, aha_resid_norm(&ra, M, st));
         c->last_flops += 4.0 * T * (double)max_lk * QD * B;
     }
     // ---- heads on the last token of every stream
-    if (out_scores || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, out_scores, out_raw, st));
+    if (out_scores || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, out_scores, out_raw, c->bar_err, st));
     if (out_last_hidden)
         HIPCHK(c, hipMemcpy2DAsync(out_last_hidden, (size_t)H * 2, c->xn + (size_t)(T - 1) * H, (size_t)T * H * 2, (size_t)H * 2, B,
                                    hipMemcpyDeviceToDevice, st));
@@ -890,7 +929,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
 
 extern "C" int aha_lm_heads_all(aha_ctx* c, float* out_raw, aha_hip_stream st) {
     if (!c || !out_raw || c->last_B == 0) return AHA_E_INVAL;
-    HIPCHK(c, aha_heads(c->xn, c->d.hidden, 0, 1, c->last_B * c->last_T, c->heads_w, c->d.hidden, nullptr, out_raw, (hipStream_t)st));
+    HIPCHK(c, aha_heads(c->xn, c->d.hidden, 0, 1, c->last_B * c->last_T, c->heads_w, c->d.hidden, nullptr, out_raw, c->bar_err, (hipStream_t)st));
     return 0;
 }
 

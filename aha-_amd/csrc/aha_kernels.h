@@ -53,6 +53,16 @@ struct ResidNormArgs {
     int H; float eps;
 };
 
+// fused MLP block (lm_fused.hip): resid_norm -> gate/up + SwiGLU -> down, one launch, two grid barriers
+struct MlpBlockArgs {
+    ResidNormArgs rn; int M;
+    GemmWsArgs gu; int gu_blocks;                 // gate/up: virtual workgroups (8 waves x 2 n-tiles each), S = 1
+    GemmWsArgs dn; int dn_blocks_x;               // down: virtual grid (dn_blocks_x, dn.S)
+    unsigned long long* ctr; unsigned long long base;   // arrival counters ([0] top, [16*(1+g)] group g) and the top value before this launch
+    int per_group;                                // workgroups per arrival group (0: flat counter)
+    int* err;                                     // set to 1 if a barrier wait timed out
+};
+
 // frame ingest (ingest.hip): one source frame -> one [3,S,S] canvas
 struct IngestArgs {
     const uint8_t* src; int h, w, src_bgr;       // uint8 [h][w][3]; src_bgr: channels arrive B,G,R
@@ -85,11 +95,13 @@ hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo
 hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st);
 hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D, hipStream_t st);
-hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H, float* scores, float* raw, hipStream_t st);
+hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H, float* scores, float* raw, const int* poison, hipStream_t st);
 hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st);
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st);
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);
 hipError_t aha_ingest_launch(const IngestArgs* a, int method, hipStream_t st);
+hipError_t aha_lm_mlp_block(MlpBlockArgs* p, int grid, hipStream_t st);
+int aha_lm_mlp_block_counter_step(int grid);
 }

@@ -54,88 +54,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
 // lin_bf16 != null replaces the slab sum (tiled-GEMM fallback path).
 // ---------------------------------------------------------------------------------------------
 
-// One 16-B chunk of the row per thread (blockDim = H/8 rounded up to waves, <= 1024): every slab
-// load of the thread is independent and issued back to back, so the kernel costs about two
-// memory latencies instead of S of them.
-static __device__ __forceinline__ float block_sum_any(float v, float* red) {
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < nw; ++i) t += red[i];
-    return t;
-}
+#include "resid_norm_body.h"
 
 __global__ __launch_bounds__(512) void resid_norm_kernel(ResidNormArgs a) {
     __shared__ float red[16];
-    const int row = blockIdx.x, nch = a.H >> 3;
-    float ss = 0.f;
-    for (int c0 = 0; c0 < nch; c0 += blockDim.x) {          // one pass when H/8 <= blockDim
-        const int c = c0 + threadIdx.x;
-        float f8[8];
-        if (c < nch) {
-            float lin[8];
-            if (a.partial) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) lin[e] = 0.f;
-                const float* p = a.partial + (long)row * a.ldp + c * 8;
-                for (int s0 = 0; s0 < a.S; s0 += 8) {
-                    f32x4 p0[8], p1[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (s0 + j < a.S) {
-                            p0[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride);
-                            p1[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride + 4);
-                        }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (s0 + j < a.S) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { lin[e] += p0[j][e]; lin[4 + e] += p1[j][e]; }
-                        }
-                }
-            } else {
-                const bf16x8 lv = *reinterpret_cast<const bf16x8*>(a.lin_bf16 + (long)row * a.ldl + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) lin[e] = bf2f(lv[e]);
-            }
-            const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
-            bf16x8 ho;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = rbf(bf2f(hh[e]) + rbf(lin[e]));
-                f8[e] = f;
-                ho[e] = f2bf(f);
-                ss += f * f;
-            }
-            *reinterpret_cast<bf16x8*>(a.h + (long)row * a.ldh + c * 8) = ho;
-        }
-        if (nch <= (int)blockDim.x) {                       // common case: keep the row in registers
-            ss = block_sum_any(ss, red);
-            const float rstd = rsqrtf(ss / (float)a.H + a.eps);
-            if (c < nch) {
-                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));
-                *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
-            }
-            return;
-        }
-    }
-    // H/8 > blockDim (H > 8192): second pass re-reads the updated residual row
-    ss = block_sum_any(ss, red);
-    const float rstd = rsqrtf(ss / (float)a.H + a.eps);
-    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
-        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(hh[e]) * rstd));
-        *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
-    }
+    resid_norm_row(a, blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,7 +183,7 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(StepDesc sd, const b
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void heads_kernel(const bf16* __restrict__ xn, int ldx, int row_first, int row_step,
                                                     const bf16* __restrict__ heads_w, int H, float* __restrict__ scores,
-                                                    float* __restrict__ raw) {
+                                                    float* __restrict__ raw, const int* __restrict__ poison) {
     __shared__ float red[4][4];
     const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16* x = xn + (long)(row_first + i * row_step) * ldx;
@@ -284,6 +207,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const bf16* __restrict__ xn,
         float l[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) l[k] = rbf(red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+        if (poison && *poison)                       // a fused kernel's grid barrier timed out earlier: never return plausible numbers
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l[k] = __builtin_nanf("");
         if (raw) { raw[i * 4 + 0] = l[0]; raw[i * 4 + 1] = l[1]; raw[i * 4 + 2] = l[2]; raw[i * 4 + 3] = l[3]; }
         if (scores) {
             const float m = fmaxf(l[0], l[1]);
@@ -504,9 +430,9 @@ hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* r
     return hipGetLastError();
 }
 hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H,
-                     float* scores, float* raw, hipStream_t st) {
+                     float* scores, float* raw, const int* poison, hipStream_t st) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(256), 0, st, xn, ldx, row_first, row_step, heads_w, H, scores, raw);
+    hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(256), 0, st, xn, ldx, row_first, row_step, heads_w, H, scores, raw, poison);
     return hipGetLastError();
 }
 hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st) {

@@ -1,0 +1,89 @@
+// resid_norm_body.h -- split-K reduce + residual add + RMSNorm of one row, shared by elementwise.hip and lm_fused.hip.
+#pragma once
+#include "aha_kernels.h"
+
+// One 16-B chunk of the row per thread (blockDim = H/8 rounded up to waves, <= 1024): every slab
+// load of the thread is independent and issued back to back, so the kernel costs about two
+// memory latencies instead of S of them.
+static __device__ __forceinline__ float block_sum_any(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
+// row) and by the fused MLP-block kernel (lm_fused.hip).  All threads of the workgroup must call it together.
+static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, const int row, float* red) {
+    const int nch = a.H >> 3;
+    float ss = 0.f;
+    for (int c0 = 0; c0 < nch; c0 += blockDim.x) {          // one pass when H/8 <= blockDim
+        const int c = c0 + threadIdx.x;
+        float f8[8];
+        if (c < nch) {
+            float lin[8];
+            if (a.partial) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lin[e] = 0.f;
+                const float* p = a.partial + (long)row * a.ldp + c * 8;
+                for (int s0 = 0; s0 < a.S; s0 += 8) {
+                    f32x4 p0[8], p1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < a.S) {
+                            p0[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride);
+                            p1[j] = *reinterpret_cast<const f32x4*>(p + (s0 + j) * a.slab_stride + 4);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < a.S) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { lin[e] += p0[j][e]; lin[4 + e] += p1[j][e]; }
+                        }
+                }
+            } else {
+                const bf16x8 lv = *reinterpret_cast<const bf16x8*>(a.lin_bf16 + (long)row * a.ldl + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lin[e] = bf2f(lv[e]);
+            }
+            const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
+            bf16x8 ho;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = rbf(bf2f(hh[e]) + rbf(lin[e]));
+                f8[e] = f;
+                ho[e] = f2bf(f);
+                ss += f * f;
+            }
+            *reinterpret_cast<bf16x8*>(a.h + (long)row * a.ldh + c * 8) = ho;
+        }
+        if (nch <= (int)blockDim.x) {                       // common case: keep the row in registers
+            ss = block_sum_any(ss, red);
+            const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+            if (c < nch) {
+                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));
+                *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+            }
+            return;
+        }
+    }
+    // H/8 > blockDim (H > 8192): second pass re-reads the updated residual row
+    ss = block_sum_any(ss, red);
+    const float rstd = rsqrtf(ss / (float)a.H + a.eps);
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+        const bf16x8 hh = *reinterpret_cast<const bf16x8*>(a.h + (long)row * a.ldh + c * 8);
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(hh[e]) * rstd));
+        *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+    }
+}
+

@@ -657,3 +657,22 @@ def test_synthetic_tvsum_eval_path_runs_end_to_end(tmp_path):
     recs = json.load(open(os.path.join(out, "predictions.json")))
     assert len(recs) == 3 and set(recs[0]) == {"video_uuid", "model_response_list", "video_duration", "true_frames_list", "debug_data"}
     assert set(recs[0]["debug_data"][0]) >= {"time", "informative_score", "relevance_score", "uncertainty_score"}
+
+
+def test_fused_mlp_block_is_bit_identical(tiny128, bench_rt):
+    """Experimental single-launch resid_norm + gate/up + down with device-scope grid barriers (lm_fused.hip, tuning
+    `fuse_mlp`; off by default because two barriers cost more than two launch boundaries): it runs the same device
+    bodies, so scores must be bit-identical to the three-launch path - which also shows the release/acquire hand-off
+    across XCDs is correct - and finite (a barrier time-out poisons the scores with NaN)."""
+    for cfg, rt in ((tiny128[0], tiny128[2]), bench_rt):
+        H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+        g = torch.Generator().manual_seed(9)
+        xs = [(torch.randn(1, T, H, generator=g) * 0.05).bfloat16().cuda() for T in (23, tf, tf, tf, 1, tf)]
+        outs = []
+        for mode in (0, 1):
+            rt.set_tuning("fuse_mlp", mode)
+            st = rt.open_stream("default_sink", 64, 4)
+            outs.append(torch.cat([rt.lm_step([st], x) for x in xs]).cpu())
+            st.close()
+        rt.set_tuning("fuse_mlp", 0)
+        assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
