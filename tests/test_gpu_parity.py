@@ -676,3 +676,30 @@ def test_fused_mlp_block_is_bit_identical(tiny128, bench_rt):
             st.close()
         rt.set_tuning("fuse_mlp", 0)
         assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_row_blocks_above_256_stay_bit_identical():
+    """8 streams x 36 tokens = 288 rows exceed the fused-SwiGLU kernel's 256-row limit, so gate/up runs as 256 + 32 rows
+    (BASELINE configs[3]'s per-GPU shape).  The batched step must equal the eight solo steps bit for bit (7B-wide
+    layers).  (A single pass through the one-tile kernel + elementwise SwiGLU was measured: also bit-identical, but 10 %
+    slower - at ~288 rows the GEMM is compute/LDS-bound, not weight-bound.)"""
+    cfg = _bench_width_cfg(2)
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=320, max_vit_frames=1, max_positions=4096)
+    H, tf, B = cfg.lm.hidden_size, cfg.frame_num_tokens, 8
+    g = torch.Generator().manual_seed(41)
+    pre = (torch.randn(B, 20, H, generator=g) * 0.3).bfloat16().cuda()
+    x = (torch.randn(B, tf, H, generator=g) * 0.3).bfloat16().cuda()
+    solo = []
+    for b in range(B):
+        st = rt.open_stream("default_sink", 128, 8)
+        rt.lm_step([st], pre[b:b + 1])
+        solo.append(rt.lm_step([st], x[b:b + 1]).clone())
+        st.close()
+    sts = [rt.open_stream("default_sink", 128, 8) for _ in range(B)]
+    rt.lm_step(sts, pre)
+    batched = rt.lm_step(sts, x)                       # 288 rows in one step
+    assert torch.isfinite(batched).all() and torch.equal(batched, torch.cat(solo))
+    for st in sts:
+        st.close()
+    rt.close()
