@@ -66,7 +66,9 @@ struct aha_ctx {
          *v_p1 = nullptr, *v_p2 = nullptr;
     // tuning
     int split[GK_COUNT] = {0, 0, 0, 0};
-    int wpb[GK_COUNT] = {4, 4, 8, 8};        // waves per workgroup per GEMM kind (measured: tools/tune_lm.py)
+    // waves per workgroup per GEMM kind (measured: tools/tune_lm.py).  gate/up: 1184 wave-tasks as 237 five-wave workgroups
+    // (one per CU on 237 CUs) instead of 148 eight-wave ones: each CU then ingests less than its ~43 GB/s ceiling.
+    int wpb[GK_COUNT] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key

@@ -76,8 +76,15 @@ static thread_local int g_wpb = 4;      // waves per workgroup for the next disp
 
 template <int MT, int NT, int KC, int EPI>
 static hipError_t launch_ws(const GemmWsArgs& a, hipStream_t st) {
-    if constexpr (MT <= 4) {            // single-stream shapes: 2-, 4- and 8-wave workgroups (tuning knob)
+    if constexpr (MT <= 4) {            // single-stream shapes: 2- to 8-wave workgroups (tuning knob)
+        // The width decides how many CUs a GEMM's wave-tasks land on: e.g. gate/up = 1184 wave-tasks = 148 x 8, 198 x 6 or
+        // 237 x 5 workgroups (one per CU); each CU ingests at most ~43-55 GB/s, so fewer waves per CU on more CUs can beat
+        // the 8-wave shape even though 8 waves share one X tile best.
         if (g_wpb == 2) return launch_ws_w<MT, NT, KC, EPI, 2>(a, st);
+        if (g_wpb == 3) return launch_ws_w<MT, NT, KC, EPI, 3>(a, st);
+        if (g_wpb == 5) return launch_ws_w<MT, NT, KC, EPI, 5>(a, st);
+        if (g_wpb == 6) return launch_ws_w<MT, NT, KC, EPI, 6>(a, st);
+        if (g_wpb == 7) return launch_ws_w<MT, NT, KC, EPI, 7>(a, st);
         if (g_wpb == 8) return launch_ws_w<MT, NT, KC, EPI, 8>(a, st);
         return launch_ws_w<MT, NT, KC, EPI, 4>(a, st);
     } else {                            // batched shapes: always 8-wave workgroups (X image shared by 8 waves)
@@ -119,7 +126,7 @@ static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
 extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 256 : 416; }
 
 extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
-    g_wpb = (wpb == 2 || wpb == 8) ? wpb : 4;
+    g_wpb = (wpb >= 2 && wpb <= 8) ? wpb : 4;
     switch (epi) {
         case EPI_PARTIAL: return dispatch_mt<1, EPI_PARTIAL>(*a, st);
         case EPI_BF16: return dispatch_mt<1, EPI_BF16>(*a, st);

@@ -15,7 +15,7 @@ prefix = (torch.randn(1, 55, H, generator=g) * 0.05).bfloat16().cuda()
 X = (torch.randn(12, tf, H, generator=g) * 0.05).bfloat16().cuda()
 outs = {}
 for mode in (0, 1, 0, 1):
-    rt.set_tuning("fuse_mlp", mode)
+    rt.set_tuning("wpb_gateup", 8 if mode else 5); rt.set_tuning("fuse_mlp", mode)
     st = rt.open_stream("default_sink", 2048, 32)
     rt.lm_step([st], prefix)
     sc = []

@@ -45,7 +45,7 @@ for spec in a.sweep.split(";"):
         rt.set_tuning(key, int(v)); t = lm_time(10); kk = kinds()
         print(f"  {key}={v:>2s}: lm_step {t:.3f} ms  kind {kk[i][0]:.1f} us {kk[i][1]:.2f} TB/s")
     if a.keep_best: pass
-    else: rt.set_tuning(key, 4 if key.startswith("wpb") else 0)
+    else: rt.set_tuning(key, {"wpb_qkv": 4, "wpb_o": 4, "wpb_gateup": 5, "wpb_down": 8}.get(key, 0))   # back to the shipped default
 fr = make_frames(32, cfg.vision.image_size, seed=0).cuda()
 for n in (1, 8, 32):
     for _ in range(2): rt.visual_embed(fr[:n])
