@@ -212,6 +212,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "time_gemm") c->time_gemm = value;
     else if (k == "fuse_static") c->fuse_static = value;
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64)
+    else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);      // 0 off, 1 auto (default), 2 force
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);

@@ -89,6 +89,7 @@ hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st);
 hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, int tile_stride, int tile_off, hipStream_t st);
 hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);
+void aha_gemm_ws_set_kc_small(int v);
 void aha_attention_set_dense_tpw(int v);
 hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd, int B, int head_dim, hipStream_t st);
 hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st);

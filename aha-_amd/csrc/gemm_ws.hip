@@ -72,6 +72,11 @@ static hipError_t launch_ws_w(const GemmWsArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// tuning "kc_small": k-steps per pipeline chunk of the NT = 1, MT <= 3 kernels (QKV, O, down at T <= 48).  Their per-wave
+// streams are short (5-9 chunks of 8 k-steps), so finer chunks fill and drain the 3-deep pipeline faster: measured LM step
+// 3.26 -> 3.20 ms with 4 (tools/tune_lm.py --sweep kc_small:8,4).  Sums do not depend on it (slices are in units of 8 k-steps).
+static int g_kc_small = 4;
+extern "C" void aha_gemm_ws_set_kc_small(int v) { g_kc_small = v == 4 ? 4 : 8; }
 static thread_local int g_wpb = 4;      // waves per workgroup for the next dispatch (2 or 4)
 
 template <int MT, int NT, int KC, int EPI>
@@ -99,6 +104,11 @@ static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
     // two X buffers fit the 160 KB LDS (checked with -Rpass-analysis=kernel-resource-usage).
     const int mt = ceil_div(a.M, 16);
     if constexpr (NT == 1) {
+        if (g_kc_small == 4 && mt <= 3) {       // default: finer pipeline chunks for the short split-K streams
+            if (mt <= 1) return launch_ws<1, 1, 4, EPI>(a, st);
+            if (mt <= 2) return launch_ws<2, 1, 4, EPI>(a, st);
+            return launch_ws<3, 1, 4, EPI>(a, st);
+        }
         if (mt <= 1) return launch_ws<1, 1, 8, EPI>(a, st);
         if (mt <= 2) return launch_ws<2, 1, 8, EPI>(a, st);
         if (mt <= 3) return launch_ws<3, 1, 8, EPI>(a, st);

@@ -40,12 +40,16 @@ base = lm_time(); k = kinds()
 print(f"default: lm_step {base:.3f} ms | " + " ".join(f"{n}:{us:.1f}us/{tb:.2f}TB/s" for n, (us, tb) in zip(["qkv", "o", "gu", "down"], k)))
 for spec in a.sweep.split(";"):
     key, vals = spec.split(":")
-    i = ["qkv", "o", "gateup", "down"].index(key.split("_", 1)[1])
+    names = ["qkv", "o", "gateup", "down"]
+    i = names.index(key.split("_", 1)[1]) if key.split("_", 1)[1] in names else -1
     for v in vals.split(","):
         rt.set_tuning(key, int(v)); t = lm_time(10); kk = kinds()
-        print(f"  {key}={v:>2s}: lm_step {t:.3f} ms  kind {kk[i][0]:.1f} us {kk[i][1]:.2f} TB/s")
+        if i >= 0:
+            print(f"  {key}={v:>2s}: lm_step {t:.3f} ms  kind {kk[i][0]:.1f} us {kk[i][1]:.2f} TB/s")
+        else:
+            print(f"  {key}={v:>2s}: lm_step {t:.3f} ms | " + " ".join(f"{n}:{us:.1f}us" for n, (us, tb) in zip(["qkv", "o", "gu", "down"], kk)))
     if a.keep_best: pass
-    else: rt.set_tuning(key, {"wpb_qkv": 4, "wpb_o": 4, "wpb_gateup": 5, "wpb_down": 8}.get(key, 0))   # back to the shipped default
+    else: rt.set_tuning(key, {"wpb_qkv": 4, "wpb_o": 4, "wpb_gateup": 5, "wpb_down": 8, "kc_small": 4}.get(key, 0))   # back to the shipped default
 fr = make_frames(32, cfg.vision.image_size, seed=0).cuda()
 for n in (1, 8, 32):
     for _ in range(2): rt.visual_embed(fr[:n])
