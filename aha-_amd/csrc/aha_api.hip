@@ -52,6 +52,15 @@ struct aha_ctx {
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
+    // HIP-graph replay of frozen TrulyStaticCache steps (tuning "use_graph"): cached executables keyed by the exact step
+    struct GraphEntry {
+        StepDesc sd; int B = 0, T = 0, epoch = 0, seen = 0; hipGraphExec_t exec = nullptr; bool failed = false;
+        double wb = 0, fl = 0; int ev_used[8] = {0}; double gk_bytes[8] = {0};      // bookkeeping of the captured step
+    };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;
+    float* graph_scores = nullptr;
+    int use_graph = 1, tune_epoch = 0;
     // fused MLP block (lm_fused.hip): device arrival counter + its host-side base, error flag, switch
     unsigned long long* bar_ctr = nullptr; unsigned long long bar_base = 0; int* bar_err = nullptr; int fuse_mlp = 0, n_cus = 0;
     struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0; };
@@ -162,6 +171,9 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if ((rc = dalloc(c, &c->logits, (size_t)AHA_MAX_B * d->vocab))) return rc;
     if ((rc = dalloc(c, &c->heads_tmp, M * 4))) return rc;
 
+    // ---- graph replay state
+    if ((rc = dalloc(c, &c->graph_scores, (size_t)AHA_MAX_B * 3))) return rc;
+    if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, AHA_E_HIP, "hipStreamCreate failed");
     // ---- fused-kernel barrier state
     if ((rc = dalloc(c, &c->bar_ctr, 16 * 17)) || (rc = dalloc(c, &c->bar_err, 1))) return rc;
     if (hipMemset(c->bar_ctr, 0, 16 * 17 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->bar_err, 0, sizeof(int)) != hipSuccess)
@@ -191,6 +203,9 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    for (auto& g : c->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) hipFree(p);
     for (int k = 0; k < GK_COUNT; ++k)
         for (auto& pr : c->ev[k]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -200,6 +215,7 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
 extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     if (!c || !key) return AHA_E_INVAL;
     std::string k(key);
+    c->tune_epoch++;                                     // captured graphs bake the launch configuration in
     if (k == "split_qkv") c->split[GK_QKV] = value;
     else if (k == "split_o") c->split[GK_O] = value;
     else if (k == "split_gateup") c->split[GK_GATEUP] = value;   // ignored by the fused SwiGLU epilogue (always 1)
@@ -211,6 +227,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
     else if (k == "fuse_static") c->fuse_static = value;
+    else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64)
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
@@ -260,6 +277,8 @@ static int pack_into(aha_ctx* c, const TMap& m, const std::string& name, int N, 
 }
 
 extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, size_t n, aha_hip_stream st_) {
+    if (c) c->tune_epoch++;                                  // captured graphs hold pointers into the old tables
+
     if (!c || !tensors) return AHA_E_INVAL;
     hipStream_t st = (hipStream_t)st_;
     HIPCHK(c, hipSetDevice(c->device));
@@ -376,6 +395,8 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
 }
 
 extern "C" int aha_ctx_set_rope_table(aha_ctx* c, const void* cosb, const void* sinb, int n_pos, aha_hip_stream st_) {
+    if (c) c->tune_epoch++;                                  // captured graphs hold pointers into the old tables
+
     if (!c || !cosb || !sinb || n_pos <= 0) return AHA_E_INVAL;
     hipStream_t st = (hipStream_t)st_;
     int rc;
@@ -838,93 +859,151 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         }
     }
 
-    // ---- residual stream <- embeds ; first RMSNorm
-    HIPCHK(c, hipMemcpyAsync(c->h, embeds, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, aha_rmsnorm(c->h, H, c->L[0].ln1, c->xn, H, M, H, d.rms_eps, st));
+    // Everything from the first RMSNorm to the heads, on stream `st`, scores to `scores_out`: run directly, or recorded
+    // into a HIP graph (below).
+    auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
+        // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
+        HIPCHK(c, aha_rmsnorm(c->h, H, c->L[0].ln1, c->xn, H, M, H, d.rms_eps, st));
 
-    // attention geometry
-    int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
-    int n_splits = ceil_div(max_lk, split_len);
-    if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
-    if (n_splits < 1) n_splits = 1;
+        // attention geometry
+        int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
+        int n_splits = ceil_div(max_lk, split_len);
+        if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
+        if (n_splits < 1) n_splits = 1;
 
-    bool frozen_all = c->fuse_static != 0;
-    for (int b = 0; b < B; ++b) frozen_all = frozen_all && sd.s[b].write_base < 0;
-    int rc;
-    for (int l = 0; l < d.layers; ++l) {
-        const LayerW& w = c->L[l];
-        // QKV projection -> split-K slabs.  When every stream of the step is a frozen TrulyStaticCache
-        // (nothing is stored, the new tokens' K/V are never read: test/static_cache.py:33-36) only the
-        // q tiles are projected (they come first in the packed q|k|v weight) and the attention kernel
-        // builds Q from the slabs itself: no K/V GEMM columns, no qkv_finish launch.
-        PackedW wq = w.qkv;
-        if (frozen_all) { wq.n_tiles = QD / 16; wq.N = QD; }
-        const int nq_ld = w.qkv.n_tiles * 16;
-        const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);      // same split as the full projection: bit-identical q
-        if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
-        AttnArgs a;
-        memset(&a, 0, sizeof(a));
-        if (!frozen_all) {
-            QkvFinishArgs qa;
-            memset(&qa, 0, sizeof(qa));
-            qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
-            qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
-            qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
-            HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
-        } else {
-            a.q_partial = c->partial; a.q_S = Sq; a.q_slab_stride = (long)M * nq_ld; a.q_ldp = nq_ld; a.q_bias = w.qkv_bias;
-            a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.n_pos = c->n_pos;
-        }
-        // attention over the stream caches
-        a.q = c->q_rot; a.q_bs = (long)T * QD; a.ldq = QD;
-        a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
-        a.part_o = c->part_o; a.part_ml = c->part_ml;
-        a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
-        a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
-        HIPCHK(c, aha_attention(&a, &sd, B, Dh, st));
-        // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
-        const int So = pick_split(c, GK_O, w.o, M, 1);
-        if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
-        ResidNormArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
-        ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
-        const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
-        // One launch for resid_norm + gate/up + down (lm_fused.hip) when the step is a single small row block and both GEMM
-        // phases fit one workgroup per CU; otherwise (and while a GEMM kind is being timed) three launches.  c->partial is
-        // shared safely: o_proj's slabs are read in phase A, down's are written in phase C, two grid barriers later.
-        const int gu_blocks = ceil_div(w.gateup.n_tiles, 16), dn_blocks = ceil_div(w.down.n_tiles, 8) * Sd;
-        const bool fuse = c->fuse_mlp && M <= 64 && !c->time_gemm && c->wpb[GK_GATEUP] == 8 && c->wpb[GK_DOWN] == 8 &&
-                          gu_blocks <= c->n_cus && dn_blocks <= c->n_cus && M <= c->n_cus;
-        if (fuse) {
-            MlpBlockArgs mb;
-            memset(&mb, 0, sizeof(mb));
-            mb.rn = ra; mb.M = M;
-            mb.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
-            mb.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
-            mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err;
-            const int grid = c->n_cus < 256 ? c->n_cus : 256;
-            HIPCHK(c, aha_lm_mlp_block(&mb, grid, st));
-            c->bar_base += (unsigned long long)aha_lm_mlp_block_counter_step(grid);
-            c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
-            c->last_flops += 2.0 * 16.0 * M * ((double)w.gateup.n_tiles * w.gateup.K + (double)w.down.n_tiles * w.down.K);
-        } else {
+        bool frozen_all = c->fuse_static != 0;
+        for (int b = 0; b < B; ++b) frozen_all = frozen_all && sd.s[b].write_base < 0;
+        int rc;
+        for (int l = 0; l < d.layers; ++l) {
+            const LayerW& w = c->L[l];
+            // QKV projection -> split-K slabs.  When every stream of the step is a frozen TrulyStaticCache
+            // (nothing is stored, the new tokens' K/V are never read: test/static_cache.py:33-36) only the
+            // q tiles are projected (they come first in the packed q|k|v weight) and the attention kernel
+            // builds Q from the slabs itself: no K/V GEMM columns, no qkv_finish launch.
+            PackedW wq = w.qkv;
+            if (frozen_all) { wq.n_tiles = QD / 16; wq.N = QD; }
+            const int nq_ld = w.qkv.n_tiles * 16;
+            const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);      // same split as the full projection: bit-identical q
+            if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
+            AttnArgs a;
+            memset(&a, 0, sizeof(a));
+            if (!frozen_all) {
+                QkvFinishArgs qa;
+                memset(&qa, 0, sizeof(qa));
+                qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+                qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+                qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+                HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
+            } else {
+                a.q_partial = c->partial; a.q_S = Sq; a.q_slab_stride = (long)M * nq_ld; a.q_ldp = nq_ld; a.q_bias = w.qkv_bias;
+                a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.n_pos = c->n_pos;
+            }
+            // attention over the stream caches
+            a.q = c->q_rot; a.q_bs = (long)T * QD; a.ldq = QD;
+            a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
+            a.part_o = c->part_o; a.part_ml = c->part_ml;
+            a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
+            a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
+            HIPCHK(c, aha_attention(&a, &sd, B, Dh, st));
+            // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
+            const int So = pick_split(c, GK_O, w.o, M, 1);
+            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+            ResidNormArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
+            ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
+            const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
+            // One launch for resid_norm + gate/up + down (lm_fused.hip) when the step is a single small row block and both GEMM
+            // phases fit one workgroup per CU; otherwise (and while a GEMM kind is being timed) three launches.  c->partial is
+            // shared safely: o_proj's slabs are read in phase A, down's are written in phase C, two grid barriers later.
+            const int gu_blocks = ceil_div(w.gateup.n_tiles, 16), dn_blocks = ceil_div(w.down.n_tiles, 8) * Sd;
+            const bool fuse = c->fuse_mlp && M <= 64 && !c->time_gemm && c->wpb[GK_GATEUP] == 8 && c->wpb[GK_DOWN] == 8 &&
+                              gu_blocks <= c->n_cus && dn_blocks <= c->n_cus && M <= c->n_cus;
+            if (fuse) {
+                MlpBlockArgs mb;
+                memset(&mb, 0, sizeof(mb));
+                mb.rn = ra; mb.M = M;
+                mb.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
+                mb.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
+                mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err;
+                const int grid = c->n_cus < 256 ? c->n_cus : 256;
+                HIPCHK(c, aha_lm_mlp_block(&mb, grid, st));
+                c->bar_base += (unsigned long long)aha_lm_mlp_block_counter_step(grid);
+                c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
+                c->last_flops += 2.0 * 16.0 * M * ((double)w.gateup.n_tiles * w.gateup.K + (double)w.down.n_tiles * w.down.K);
+            } else {
+                HIPCHK(c, aha_resid_norm(&ra, M, st));
+                // gate/up with fused SwiGLU epilogue
+                if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
+                // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
+                if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+            }
+            ra.S = Sd;
+            ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
             HIPCHK(c, aha_resid_norm(&ra, M, st));
-            // gate/up with fused SwiGLU epilogue
-            if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
-            // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
-            if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+            c->last_flops += 4.0 * T * (double)max_lk * QD * B;
         }
-        ra.S = Sd;
-        ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
-        HIPCHK(c, aha_resid_norm(&ra, M, st));
-        c->last_flops += 4.0 * T * (double)max_lk * QD * B;
+        // ---- heads on the last token of every stream
+        if (scores_out || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, scores_out, out_raw, c->bar_err, st));
+        if (out_last_hidden)
+            HIPCHK(c, hipMemcpy2DAsync(out_last_hidden, (size_t)H * 2, c->xn + (size_t)(T - 1) * H, (size_t)T * H * 2, (size_t)H * 2, B,
+                                       hipMemcpyDeviceToDevice, st));
+
+        return 0;
+    };
+
+    // ---- residual stream <- embeds
+    HIPCHK(c, hipMemcpyAsync(c->h, embeds, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
+
+    // ---- HIP-graph replay.  After its first call a TrulyStaticCache stream's StreamStep never changes (frozen prefix, nothing
+    // stored; test/static_cache.py:26-36), so a step whose streams are all frozen is the SAME ~230 launches with the same
+    // kernel arguments every frame.  The host needs ~9 us per launch and falls behind the GPU in the run of short kernels
+    // (QKV -> finish -> attention -> O -> norm: measured 175 us of idle gaps per 3.2 ms step); replaying a captured graph
+    // removes that.  Keyed by the exact StepDesc + shapes + tuning epoch; captured on a private stream the second time a key is
+    // seen (every lazily set kernel attribute has been set by then); any failure falls back to direct launches for that key.
+    bool all_frozen = true;
+    for (int b = 0; b < B; ++b) all_frozen = all_frozen && sd.s[b].write_base < 0 && sd.s[b].n_rerot == 0;
+    if (c->use_graph && all_frozen && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp) {
+        aha_ctx::GraphEntry* ge = nullptr;
+        for (auto& g : c->graphs)
+            if (g.B == B && g.T == T && g.epoch == c->tune_epoch && memcmp(&g.sd, &sd, sizeof(sd)) == 0) { ge = &g; break; }
+        if (!ge) {
+            if (c->graphs.size() >= 8) {                     // small cache: drop the oldest entry
+                if (c->graphs.front().exec) hipGraphExecDestroy(c->graphs.front().exec);
+                c->graphs.erase(c->graphs.begin());
+            }
+            c->graphs.emplace_back();
+            ge = &c->graphs.back();
+            ge->sd = sd; ge->B = B; ge->T = T; ge->epoch = c->tune_epoch;
+        }
+        if (!ge->exec && !ge->failed && ge->seen >= 1) {
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int brc = layers_and_heads(c->cap_stream, c->graph_scores);
+                const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+                ok = brc == 0 && e == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) hipGraphDestroy(graph);
+            if (!ok) { ge->exec = nullptr; ge->failed = true; (void)hipGetLastError(); }
+            ge->wb = c->last_weight_bytes; ge->fl = c->last_flops;       // what the recorded launches stream / compute
+            for (int k = 0; k < GK_COUNT; ++k) { ge->ev_used[k] = c->ev_used[k]; ge->gk_bytes[k] = c->gk_bytes[k]; }
+            c->last_weight_bytes = c->last_flops = 0;                    // the capture executed nothing
+            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
+        }
+        ge->seen++;
+        if (ge->exec) {
+            HIPCHK(c, hipGraphLaunch(ge->exec, st));
+            HIPCHK(c, hipMemcpyAsync(out_scores, c->graph_scores, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            c->last_weight_bytes = ge->wb; c->last_flops = ge->fl;
+            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = ge->ev_used[k]; c->gk_bytes[k] = ge->gk_bytes[k]; }   // captured event pairs re-record on replay
+            c->last_B = B;
+            c->last_T = T;
+            return 0;
+        }
     }
-    // ---- heads on the last token of every stream
-    if (out_scores || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, out_scores, out_raw, c->bar_err, st));
-    if (out_last_hidden)
-        HIPCHK(c, hipMemcpy2DAsync(out_last_hidden, (size_t)H * 2, c->xn + (size_t)(T - 1) * H, (size_t)T * H * 2, (size_t)H * 2, B,
-                                   hipMemcpyDeviceToDevice, st));
+    if (const int brc = layers_and_heads(st, out_scores)) return brc;
     c->last_B = B;
     c->last_T = T;
     return 0;

@@ -4,7 +4,8 @@
 A "step" = one pass of the hot path over one batch of synthetic input for every stream this rank
 owns: `--frames` uint8 frames per stream are encoded by the vision tower in one batch (the
 reference pre-encodes 32-frame batches, test/inference.py:181-185) and then scored frame by frame
-by the LM step against the stream's KV cache (the per-frame loop of test/inference.py:283-335),
+by the LM step against the stream's KV cache (the per-frame loop of test/inference.py:283-335; with the frozen static
+cache each step is replayed from a captured HIP graph, bit-identical to direct launches),
 ending when the [frames,3] score rows are host-visible.  N=1 workload = BASELINE.json configs[1]:
 SigLIP-L/14@336 + Qwen2-7B bf16, single stream, static KV cache.  With N>1 every rank runs its own
 independent stream(s) (weak scaling) and the per-step score rows are all-gathered with RCCL.
@@ -229,13 +230,11 @@ def main():
         torch.cuda.synchronize()
 
     run(a.warmup)
-    rt.set_tuning("time_gemm", 1 << 2)                             # HIP events around the gate/up launches
     sync()
     t0 = time.perf_counter()
     run(a.steps)
     sync()
     dt = time.perf_counter() - t0
-    rt.set_tuning("time_gemm", 0)
     if world > 1:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,8 +242,21 @@ def main():
         dt = t.item()
     assert torch.isfinite(scores_host).all()
 
-    # dominant kernel: the gate/up weight-streaming GEMM (fused SwiGLU) of the LAST timed LM step
-    g_ms, g_n, g_bytes = rt.last_gemm_time(2)
+    # Dominant kernel: the gate/up weight-streaming GEMM (fused SwiGLU).  In the timed region the LM steps are replayed from
+    # a HIP graph and share the GPU with the next batch's vision tower, so the kernel is timed with HIP events (on its launch
+    # stream, around each of its 28 launches) on identical LM steps issued right after the region, with nothing else in
+    # flight: same process, same buffers, same stream state.  Average over 4 steps (112 launches).
+    emb_last = emb_buf[(a.steps - 1) & 1].view(B, F, tf, H)
+    rt.set_tuning("time_gemm", 1 << 2)
+    g_ms = g_bytes = 0.0
+    g_n = 0
+    for i in range(6):
+        rt.lm_step(streams, emb_last[:, i % F].contiguous())
+        torch.cuda.synchronize()
+        if i >= 2:                                                    # first two: direct launch, then graph capture
+            ms, n, by = rt.last_gemm_time(2)
+            g_ms, g_n, g_bytes = g_ms + ms, g_n + n, g_bytes + by
+    rt.set_tuning("time_gemm", 0)
     wb, kvb, fl = rt.last_step_work()
 
     # p50 per-frame latency: ViT(1 frame) + LM step + score D2H, events on the launch stream

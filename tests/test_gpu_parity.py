@@ -709,3 +709,32 @@ def test_row_blocks_above_256_stay_bit_identical():
     for st in sts:
         st.close()
     rt.close()
+
+
+def test_graph_replay_of_frozen_static_steps_is_bit_identical(tiny128, bench_rt):
+    """After its first call a TrulyStaticCache step descriptor never changes, so the step is replayed from a captured HIP
+    graph (tuning `use_graph`, on by default; captured the second time a step shape is seen).  Replay must give the
+    same bits as direct launches, also when the frozen stream is listed several times, when the RoPE position offset
+    changes (a different key) and after a reset (new prefix length)."""
+    for cfg, rt in ((tiny128[0], tiny128[2]), bench_rt):
+        H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+        g = torch.Generator().manual_seed(13)
+        pre = [(torch.randn(1, n, H, generator=g) * 0.05).bfloat16().cuda() for n in (23, 31)]
+        xs = (torch.randn(6, tf, H, generator=g) * 0.05).bfloat16().cuda()
+        outs = []
+        for mode in (0, 1):
+            rt.set_tuning("use_graph", mode)
+            st = rt.open_stream("static", 2048, 0)
+            got = []
+            for p in pre:                                   # two "videos": reset, new frozen prefix
+                st.reset()
+                rt.lm_step([st], p)
+                got += [rt.lm_step([st], xs[i:i + 1]).clone() for i in range(6)]          # steps 3.. come from the graph
+                got.append(rt.lm_step([st, st], xs[0:2].contiguous()).clone().view(1, -1))  # frozen stream listed twice
+                st.set_position_offset(tf - 1)
+                got += [rt.lm_step([st], xs[i:i + 1, -1:].contiguous()).clone() for i in range(4)]
+                st.set_position_offset(0)
+            outs.append(torch.cat([o.view(-1) for o in got]).cpu())
+            st.close()
+        rt.set_tuning("use_graph", 1)
+        assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
