@@ -74,7 +74,14 @@ int aha_ctx_set_rope_table(aha_ctx* ctx, const void* cos_bf16, const void* sin_b
 int aha_ctx_set_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T, const void* cos_bf16,
                                  const void* sin_bf16, aha_hip_stream st);
 int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
-/* tuning knobs: "split_qkv", "split_o", "split_down", "attn_split_len" (0 = heuristic) */
+/* tuning knobs (all optional; defaults are the measured best, DESIGN.md sections 4/5/8):
+ *   "split_qkv" / "split_o" / "split_down"  split-K factors of the weight-streaming GEMMs (0 = heuristic; never depends on M)
+ *   "wpb_qkv" / "wpb_o" / "wpb_gateup" / "wpb_down"  waves per workgroup (2..8) = over how many CUs a GEMM's wave-tasks spread
+ *   "kc_small"        k-steps per pipeline chunk of the small split-K GEMMs (4 or 8)
+ *   "attn_split_len"  keys per attention split (0 = heuristic)      "attn_tpw"  query tiles per wave of the dense (ViT) attention
+ *   "tile_dma"        tiled-GEMM variant (0 register-staged, 1 auto, >= 2 forced variant id)
+ *   "use_graph"       1: replay frozen static-cache steps from a captured HIP graph      "fuse_static" / "fuse_mlp"  experiments
+ *   "time_gemm"       bit k: bracket GEMM kind k's launches with HIP events (aha_lm_last_gemm_time) */
 int aha_ctx_set_tuning(aha_ctx* ctx, const char* key, int value);
 void aha_ctx_destroy(aha_ctx* ctx);
 const char* aha_last_error(aha_ctx* ctx);
