@@ -748,11 +748,11 @@ static int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_
     const int nc = w.KS / 8;                  // slices are placed in units of 8 k-steps (gemm_ws.hip), independent of KC
     int S = c->split[kind];
     if (S <= 0) {
-        // about one workgroup per CU: enough streams to fill HBM, and the fewest slabs for the reducing kernel
-        // (resid_norm / qkv_finish ingest S slabs per row at the per-CU ceiling).  Measured on the 7B shapes: O 8 -> 4 and
-        // QKV 7 -> 3 are each ~1 % of the LM step faster; down stays at 8 (28 x 8 = 224 workgroups).
+        // ~2 four-wave workgroups per CU.  (One per CU - O 8 -> 4, QKV 7 -> 3, fewer slabs for the reducing kernels - measured
+        // ~1 % faster on the single-stream step but 3-5 % slower on the batched shapes, which run 8-wave workgroups and were left
+        // under-filled; S may not depend on M, so the batched-friendly value stays.)
         const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);
-        S = (c->n_cus > 0 ? c->n_cus : 256) / (nblk > 0 ? nblk : 1);
+        S = 512 / (nblk > 0 ? nblk : 1);
         if (S > 8) S = 8;
     }
     if (S > nc) S = nc;
