@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
     p.add_argument("--tile-dma", type=int, default=-1, help="experiment: force a tiled-GEMM variant in the vision tower")
     p.add_argument("--vit-cus", type=int, default=0,
                    help="experiment: restrict the vision stream to this many CUs (HIP CU mask, XCD-balanced)")
@@ -137,13 +139,30 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     local = local % max(1, torch.cuda.device_count())            # --backend gloo rehearsal: several ranks on one GPU
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":                                   # RCCL over xGMI
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group("gloo")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when the communicator is created (at the first collective): keep stdout for
+        # the ONE JSON line by pointing fd 1 at stderr until the communicator exists.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            torch.cuda.set_device(local)
+            if a.backend == "nccl":                               # RCCL over xGMI
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     from aha_amd.sharding import gather_scores
@@ -218,14 +237,14 @@ def main():
             for i in range(F):
                 scores_dev[i] = rt.lm_step(streams, emb[:, i].contiguous())
             emb_free[k & 1].record(main_stream)
-            if world > 1:
+            if use_dist:
                 # one collective per step on [F, B, 3] score rows -> [F, B*world, 3] in global stream order
                 loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
                 run.last_global = gather_scores(loc, n_streams_global)
             scores_host.copy_(scores_dev, non_blocking=True)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -235,7 +254,7 @@ def main():
     run(a.steps)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert run.last_global.shape == (F, n_streams_global, 3) and torch.isfinite(run.last_global).all()
@@ -362,7 +381,7 @@ def main():
     for s in streams:
         s.close()
     rt.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
