@@ -128,12 +128,14 @@ static hipError_t dispatch_mt(const GemmWsArgs& a, hipStream_t st) {
         if (mt <= 8) return launch_ws<8, 2, 2, EPI>(a, st);
         if (mt <= 12) return launch_ws<12, 2, 1, EPI>(a, st);
         if (mt <= 16) return launch_ws<16, 2, 1, EPI>(a, st);
+        if (mt <= 18) return launch_ws<18, 2, 1, EPI>(a, st);
+        if (mt <= 20) return launch_ws<20, 2, 1, EPI>(a, st);
     }
     return hipErrorInvalidValue;               // caller chunks M
 }
 
 // Largest M each epilogue supports in one launch (the host loops over row chunks beyond it).
-extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 256 : 416; }
+extern "C" int aha_gemm_ws_max_m(int epi) { return epi == EPI_SWIGLU ? 320 : 416; }
 
 extern "C" hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
     g_wpb = (wpb >= 2 && wpb <= 8) ? wpb : 4;

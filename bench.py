@@ -174,7 +174,7 @@ def main():
     cache = None if a.cache == "none" else a.cache
     n_sys, n_query = 35, 20
     w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=True)
-    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max(B * (tf + n_sys), 256), max_vit_frames=min(32, B * F),
+    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max(B * (tf + n_sys), 320), max_vit_frames=min(32, B * F),
                  max_positions=cfg.lm.max_position_embeddings)
     if a.tile_dma >= 0:
         rt.set_tuning("tile_dma", a.tile_dma)
@@ -298,7 +298,7 @@ def main():
     # share one pass over the weights by listing the frozen stream G times in a single aha_lm_step.
     static_batched = None
     if a.cache == "static" and B == 1:
-        G = max(1, 256 // tf)
+        G = max(1, 320 // tf)                                          # rows one fused gate/up pass holds (gemm_ws: 20 row tiles)
         def step_batched():
             emb = rt.visual_embed(frames_all).view(F, tf, H)
             for i in range(0, F, G):

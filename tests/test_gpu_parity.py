@@ -690,10 +690,9 @@ def test_fused_mlp_block_is_bit_identical(tiny128, bench_rt):
 
 
 def test_row_blocks_above_256_stay_bit_identical():
-    """8 streams x 36 tokens = 288 rows exceed the fused-SwiGLU kernel's 256-row limit, so gate/up runs as 256 + 32 rows
-    (BASELINE configs[3]'s per-GPU shape).  The batched step must equal the eight solo steps bit for bit (7B-wide
-    layers).  (A single pass through the one-tile kernel + elementwise SwiGLU was measured: also bit-identical, but 10 %
-    slower - at ~288 rows the GEMM is compute/LDS-bound, not weight-bound.)"""
+    """8 streams x 36 tokens = 288 rows (BASELINE configs[3]'s per-GPU shape) run gate/up in one pass of the 18-row-tile
+    fused-SwiGLU instantiation (it used to be 256 + 32 rows, streaming the weights twice).  The batched step must equal the
+    eight solo steps bit for bit (7B-wide layers)."""
     cfg = _bench_width_cfg(2)
     w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
     rt = _rt(cfg, w, max_step_tokens=320, max_vit_frames=1, max_positions=4096)
