@@ -228,7 +228,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "time_gemm") c->time_gemm = value;
     else if (k == "fuse_static") c->fuse_static = value;
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
-    else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64)
+    else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);      // 0 off, 1 auto (default), 2 force
@@ -928,7 +928,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 mb.rn = ra; mb.M = M;
                 mb.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
                 mb.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
-                mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err;
+                mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err; mb.sc1 = c->fuse_mlp >= 2;
                 const int grid = c->n_cus < 256 ? c->n_cus : 256;
                 HIPCHK(c, aha_lm_mlp_block(&mb, grid, st));
                 c->bar_base += (unsigned long long)aha_lm_mlp_block_counter_step(grid);

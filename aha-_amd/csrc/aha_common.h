@@ -24,6 +24,19 @@ static __device__ __forceinline__ float rbf(float x) {
     return __uint_as_float(u & 0xFFFF0000u);
 }
 
+// 16-byte write-through store (buffer_store_dwordx4 ... sc1): the bytes reach memory without a release fence, for tensors
+// handed to other workgroups inside one launch (cdna_hip_programming.md G16, recipe R1).  byte_off < 4 GB.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+static __device__ __forceinline__ void store16_sc1(void* base, long byte_off, u32x4_t v) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
+}
+static __device__ __forceinline__ void store8_sc1(void* base, long byte_off, unsigned long long v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, (int)byte_off, 0, 16);
+}
+
 static __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     // D[16x16] += A[16x32] * B[32x16]; lane l: A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];
     // C/D: col = l&15, row = (l>>4)*4 + reg

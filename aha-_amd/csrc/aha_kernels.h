@@ -60,6 +60,7 @@ struct MlpBlockArgs {
     GemmWsArgs dn; int dn_blocks_x;               // down: virtual grid (dn_blocks_x, dn.S)
     unsigned long long* ctr; unsigned long long base;   // arrival counters ([0] top, [16*(1+g)] group g) and the top value before this launch
     int per_group;                                // workgroups per arrival group (0: flat counter)
+    int sc1;                                      // 1: xn / act stored write-through, barriers without release fences
     int* err;                                     // set to 1 if a barrier wait timed out
 };
 

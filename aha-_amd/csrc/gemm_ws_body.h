@@ -20,7 +20,7 @@ struct WsCfg {
 // weights do not depend on the previous phase, so they stream during the wait) and the first X tile is loaded after
 // it; without it the order is the stand-alone kernel's (X first, so that the first LDS store does not wait for the
 // weights).
-template <int MT, int NT, int KC, int EPI, int WPB, bool PREFETCH_W, typename Between>
+template <int MT, int NT, int KC, int EPI, int WPB, bool PREFETCH_W, typename Between, bool OUT_SC1 = false>
 static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const int bx, const int by, bf16* xs, Between between) {
     using C = WsCfg<MT, NT, KC, WPB>;
 
@@ -195,7 +195,8 @@ static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const i
                 const float u = rbf(acc[m][NT - 1][e]);         // up_proj output (bf16)
                 o[e] = f2bf(sg * u);
             }
-            *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
+            if constexpr (OUT_SC1) store8_sc1(a.out, ((long)row * a.ldo + col) * 2, __builtin_bit_cast(unsigned long long, o));   // handed off inside the launch
+            else *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
         }
     } else {  // EPI_F32_RBF: fp32 logits that passed through a bf16 Linear output
 #pragma unroll

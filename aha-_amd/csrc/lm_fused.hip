@@ -29,13 +29,16 @@ struct GridBarrier {
     unsigned long long target;       // top-counter value at which everyone has arrived
     int* err;
     int per_group;                   // workgroups per group (grid / NG), 0 = flat counter (ctr[0] counts workgroups)
+    bool release;                    // false: every handed-off store was write-through (sc1), no release fence needed
     static constexpr int NG = 16;
     __device__ __forceinline__ void arrive() const {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's stores of the finished phase
         __syncthreads();
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (release) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (per_group > 0) {
                 const unsigned long long old = __hip_atomic_fetch_add(ctr + 16 * (1 + (blockIdx.x % NG)), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((int)(old % (unsigned long long)per_group) == per_group - 1)
@@ -76,7 +79,9 @@ struct MlpCfg {
     static constexpr int LDS_BYTES = XS_BYTES + 64;
 };
 
-template <int MT>
+// SC1: the two tensors that cross a barrier (xn: A -> B, act: B -> C) are stored write-through and the barriers skip the
+// release fence (one L2 write-back per workgroup per barrier); the waiters' acquire stays.
+template <int MT, bool SC1>
 __global__ __launch_bounds__(512, 2) void lm_mlp_block_kernel(MlpBlockArgs p) {
     using C = MlpCfg<MT>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -85,28 +90,29 @@ __global__ __launch_bounds__(512, 2) void lm_mlp_block_kernel(MlpBlockArgs p) {
     const int wg = blockIdx.x, P = gridDim.x;
 
     // ---- phase A: o_proj slabs + residual -> h, post-attention RMSNorm -> xn (one row per workgroup)
-    for (int row = wg; row < p.M; row += P) resid_norm_row(p.rn, row, red);
+    for (int row = wg; row < p.M; row += P) resid_norm_row<SC1>(p.rn, row, red);
 
     // ---- phase B: gate/up + SwiGLU (needs every row of xn): arrive, prefetch weights, wait
     const int pg = p.per_group;
     const unsigned long long per_bar = pg > 0 ? GridBarrier::NG : (unsigned long long)P;   // top-counter increments per barrier
-    GridBarrier b1{p.ctr, p.base + per_bar, p.err, pg};
+    GridBarrier b1{p.ctr, p.base + per_bar, p.err, pg, !SC1};
     b1.arrive();
-    if (wg < p.gu_blocks) gemm_ws_body<MT, 2, C::KC_GU, EPI_SWIGLU, 8, true>(p.gu, wg, 0, xs, [&] { b1.wait(); });
+    auto w1 = [&] { b1.wait(); };
+    if (wg < p.gu_blocks) gemm_ws_body<MT, 2, C::KC_GU, EPI_SWIGLU, 8, true, decltype(w1), SC1>(p.gu, wg, 0, xs, w1);
     else b1.wait();
 
     // ---- phase C: down projection, split-K slabs (needs every column of act)
-    GridBarrier b2{p.ctr, p.base + 2 * per_bar, p.err, pg};
+    GridBarrier b2{p.ctr, p.base + 2 * per_bar, p.err, pg, !SC1};
     b2.arrive();
     if (wg < p.dn_blocks_x * p.dn.S) gemm_ws_body<MT, 1, C::KC_DN, EPI_PARTIAL, 8, true>(p.dn, wg % p.dn_blocks_x, wg / p.dn_blocks_x, xs, [&] { b2.wait(); });
     else b2.wait();
 }
 
-template <int MT>
+template <int MT, bool SC1>
 static hipError_t launch_mlp(const MlpBlockArgs& p, int grid, hipStream_t st) {
     using C = MlpCfg<MT>;
     static bool attr_set = false;
-    auto kern = lm_mlp_block_kernel<MT>;
+    auto kern = lm_mlp_block_kernel<MT, SC1>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -127,10 +133,18 @@ extern "C" hipError_t aha_lm_mlp_block(MlpBlockArgs* p, int grid, hipStream_t st
     p->dn_blocks_x = ceil_div(p->dn.n_tiles, 8);
     p->per_group = grid % GridBarrier::NG == 0 ? grid / GridBarrier::NG : 0;
     if (p->gu.S != 1 || p->gu_blocks > grid || p->dn_blocks_x * p->dn.S > grid || p->M > grid) return hipErrorInvalidValue;
+    if (p->sc1) {
+        switch (mt) {
+            case 1: return launch_mlp<1, true>(*p, grid, st);
+            case 2: return launch_mlp<2, true>(*p, grid, st);
+            case 3: return launch_mlp<3, true>(*p, grid, st);
+            default: return launch_mlp<4, true>(*p, grid, st);
+        }
+    }
     switch (mt) {
-        case 1: return launch_mlp<1>(*p, grid, st);
-        case 2: return launch_mlp<2>(*p, grid, st);
-        case 3: return launch_mlp<3>(*p, grid, st);
-        default: return launch_mlp<4>(*p, grid, st);
+        case 1: return launch_mlp<1, false>(*p, grid, st);
+        case 2: return launch_mlp<2, false>(*p, grid, st);
+        case 3: return launch_mlp<3, false>(*p, grid, st);
+        default: return launch_mlp<4, false>(*p, grid, st);
     }
 }

@@ -18,6 +18,9 @@ static __device__ __forceinline__ float block_sum_any(float v, float* red) {
 
 // One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
 // row) and by the fused MLP-block kernel (lm_fused.hip).  All threads of the workgroup must call it together.
+// XN_SC1: store xn write-through (buffer_store ... sc1) because another workgroup of the SAME launch reads it behind a grid
+// barrier without a release fence (lm_fused.hip).
+template <bool XN_SC1 = false>
 static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, const int row, float* red) {
     const int nch = a.H >> 3;
     float ss = 0.f;
@@ -69,7 +72,8 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));
-                *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+                if constexpr (XN_SC1) store16_sc1(a.xn, ((long)row * a.ldx + c * 8) * 2, __builtin_bit_cast(u32x4_t, o));
+                else *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
             }
             return;
         }

@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(3)
 prefix = (torch.randn(1, 55, H, generator=g) * 0.05).bfloat16().cuda()
 X = (torch.randn(12, tf, H, generator=g) * 0.05).bfloat16().cuda()
 outs = {}
-for mode in (0, 1, 0, 1):
+for mode in (0, 1, 2, 0, 1, 2):
     rt.set_tuning("wpb_gateup", 8 if mode else 5); rt.set_tuning("fuse_mlp", mode)
     st = rt.open_stream("default_sink", 2048, 32)
     rt.lm_step([st], prefix)
@@ -30,4 +30,4 @@ for mode in (0, 1, 0, 1):
     print(f"fuse_mlp={mode}: {dt * 1e3:.3f} ms per LM step; finite {bool(torch.isfinite(sc).all())}", flush=True)
     outs.setdefault(mode, sc)
     st.close()
-print("fused == unfused bit-exact:", torch.equal(outs[0], outs[1]), "max diff", (outs[0] - outs[1]).abs().max().item())
+print("fused (fences) == unfused bit-exact:", torch.equal(outs[0], outs[1]), "| fused (sc1 hand-offs) == unfused:", torch.equal(outs[0], outs[2]))
