@@ -355,7 +355,7 @@ def main():
             "metric": "frames/sec scored (whole node)", "value": total_frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {cfg.name} shapes (ViT-L/14@{cfg.vision.image_size} + Qwen2-7B dims), "
+            "config": {"workload": f"configs[1]: {cfg.name} shapes ({'so400m' if cfg.vision.hidden_size == 1152 else 'ViT-L'}/14@{cfg.vision.image_size} + Qwen2-7B dims), "
                                    f"{B} stream(s)/GPU, {a.cache} KV cache (W={a.window}), {F} frames/stream/step, "
                                    f"Tf={tf} tokens/frame, seeded random weights",
                        "frames_per_step": F * B * world, "streams_per_gpu": B, "cache": a.cache, "vit_lm_overlap": not a.no_overlap,
