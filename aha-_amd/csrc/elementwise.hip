@@ -108,6 +108,7 @@ __global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, StepD
     for (int it = blockIdx.y * blockDim.x + tid; it < qk_items + v_items; it += gridDim.y * blockDim.x) {
         if (it < qk_items) {
             const int head = it / IPH, d = (it % IPH) * 4;     // head < Hq: query head, else key head
+            if (head >= a.Hq && !store_kv) continue;            // frozen static cache: K is neither stored nor (then) projected
             const int col = head * D + d;
             float x1[4], x2[4];
             fetch4(col, x1);

@@ -454,14 +454,14 @@ def test_reference_faithful_vision_shapes_head_dim_72():
 
 
 def test_frozen_static_fusion_is_bit_identical(tiny128):
-    """Opt-in `fuse_static`: frozen TrulyStaticCache steps skip the K/V projection and build Q inside the
-    attention kernel from the split-K slabs - must not change a single bit."""
+    """Opt-in `fuse_static`: frozen TrulyStaticCache steps skip the (dead) K/V projection (2) and additionally build Q
+    inside the attention kernel from the split-K slabs (1) - neither may change a single bit."""
     cfg, w, rt = tiny128
     g = torch.Generator().manual_seed(12)
     prefix = (torch.randn(1, 11, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16().cuda()
     xs = (torch.randn(5, 9, cfg.lm.hidden_size, generator=g) * 0.5).bfloat16().cuda()
     out = {}
-    for fuse in (0, 1):
+    for fuse in (0, 1, 2):
         rt.set_tuning("fuse_static", fuse)
         st = rt.open_stream("static", 64, 0)
         rt.lm_step([st], prefix)
@@ -470,6 +470,7 @@ def test_frozen_static_fusion_is_bit_identical(tiny128):
         st.close()
     rt.set_tuning("fuse_static", 0)
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[(1, "b")]) and torch.equal(out[0], out[(0, "b")])
+    assert torch.equal(out[0], out[2]) and torch.equal(out[0], out[(2, "b")])
 
 
 def test_driver_static_batched_equals_sequential(tiny):
