@@ -37,7 +37,9 @@ struct aha_ctx {
     aha_model_desc d;
     int device = 0;
     std::string err;
-    int grid = 0, Np = 0, Kp = 0, Fp = 0, go = 0, Tf = 0;   // Kp / Fp: patch-vector / MLP width padded to whole 64-wide k-tiles
+    int grid = 0, Np = 0, Tt = 0, Kp = 0, Fp = 0, go = 0, Tf = 0;   // Tt: tower tokens per frame (Np, or Np + 1 with CLIP's class token)
+    bf16 *cls_emb = nullptr, *pre_ln_w = nullptr, *pre_ln_b = nullptr, *v_patch = nullptr;   // CLIP only
+    float px_mean[3] = {0.5f, 0.5f, 0.5f}, px_std[3] = {0.5f, 0.5f, 0.5f};   // Kp / Fp: patch-vector / MLP width padded to whole 64-wide k-tiles
     bool weights_loaded = false;
     // LM weights
     std::vector<LayerW> L;
@@ -145,6 +147,12 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if (d->hidden > 8192) return fail(c, AHA_E_INVAL, "hidden > 8192 unsupported");
     c->grid = d->image_size / d->patch_size;
     c->Np = c->grid * c->grid;
+    if (d->v_kind != AHA_VISION_SIGLIP && d->v_kind != AHA_VISION_CLIP) return fail(c, AHA_E_INVAL, "unknown v_kind");
+    c->Tt = c->Np + (d->v_kind == AHA_VISION_CLIP ? 1 : 0);
+    if (d->v_kind == AHA_VISION_CLIP) {                  // transformers.utils.constants OPENAI_CLIP_MEAN / OPENAI_CLIP_STD
+        const float m[3] = {0.48145466f, 0.4578275f, 0.40821073f}, sd[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+        for (int i = 0; i < 3; ++i) { c->px_mean[i] = m[i]; c->px_std[i] = sd[i]; }
+    }
     // K of the patch embedding (3*P*P = 588) and of fc2 (so400m: 4304) padded with zeros to whole k-tiles so that
     // every tower GEMM is eligible for the LDS-DMA kernels (gemm_tile.hip); zero columns add exact zeros.
     c->Kp = round_up(3 * d->patch_size * d->patch_size, 64);
@@ -185,8 +193,9 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     }
 
     // ---- ViT workspaces
-    const size_t R = (size_t)d->max_vit_frames * c->Np, Dv = d->v_hidden;
+    const size_t R = (size_t)d->max_vit_frames * c->Tt, Dv = d->v_hidden;
     if ((rc = dalloc(c, &c->v_a0, R * c->Kp))) return rc;
+    if (d->v_kind == AHA_VISION_CLIP && (rc = dalloc(c, &c->v_patch, R * Dv))) return rc;      // patch embeddings before the class token is appended
     if ((rc = dalloc(c, &c->v_x, R * Dv))) return rc;
     if ((rc = dalloc(c, &c->v_h, R * Dv))) return rc;
     if ((rc = dalloc(c, &c->v_qkv, R * 3 * Dv))) return rc;
@@ -347,8 +356,22 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
         HIPCHK(c, hipMemsetAsync(c->patch_w, 0, (size_t)Dv * c->Kp * 2, st));
         HIPCHK(c, hipMemcpy2DAsync(c->patch_w, (size_t)c->Kp * 2, t->data, (size_t)PP3 * 2, (size_t)PP3 * 2, Dv, hipMemcpyDeviceToDevice, st));
     }
-    if ((rc = copy_vec(c, m, "vision.embeddings.patch_embedding.bias", Dv, &c->patch_b, st))) return rc;
-    if ((rc = copy_vec(c, m, "vision.embeddings.position_embedding.weight", (int64_t)c->Np * Dv, &c->pos_emb, st))) return rc;
+    if (d.v_kind == AHA_VISION_CLIP) {
+        // CLIPVisionEmbeddings: no patch bias; class_embedding; Np + 1 positions with the class token's row FIRST in the
+        // checkpoint - stored here patches first, class token last (the tower's internal token order, see vit_tower)
+        c->patch_b = nullptr;
+        if ((rc = copy_vec(c, m, "vision.embeddings.class_embedding", Dv, &c->cls_emb, st))) return rc;
+        const aha_tensor_view* tp = need(c, m, "vision.embeddings.position_embedding.weight", 2, c->Tt, Dv);
+        if (!tp) return AHA_E_NOENT;
+        if ((rc = dalloc(c, &c->pos_emb, (size_t)c->Tt * Dv))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->pos_emb, (const bf16*)tp->data + Dv, (size_t)c->Np * Dv * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->pos_emb + (size_t)c->Np * Dv, tp->data, (size_t)Dv * 2, hipMemcpyDeviceToDevice, st));
+        if ((rc = copy_vec(c, m, "vision.pre_layrnorm.weight", Dv, &c->pre_ln_w, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.pre_layrnorm.bias", Dv, &c->pre_ln_b, st))) return rc;
+    } else {
+        if ((rc = copy_vec(c, m, "vision.embeddings.patch_embedding.bias", Dv, &c->patch_b, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.embeddings.position_embedding.weight", (int64_t)c->Np * Dv, &c->pos_emb, st))) return rc;
+    }
     c->V.resize(d.v_layers);
     for (int l = 0; l < d.v_layers; ++l) {
         VLayerW& w = c->V[l];
@@ -604,26 +627,36 @@ static hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ld
 
 static int vit_tower(aha_ctx* c, const uint8_t* frames, int n, hipStream_t st) {
     const aha_model_desc& d = c->d;
-    const int Dv = d.v_hidden, rows = n * c->Np, vhd = Dv / d.v_heads;
-    HIPCHK(c, aha_im2col_norm(frames, n, d.image_size, d.patch_size, c->Kp, c->v_a0, st));
-    HIPCHK(c, tile_gemm(c->v_a0, c->Kp, rows, c->patch_w, c->Kp, Dv, c->Kp, c->v_x, Dv, c->patch_b, ACT_NONE, nullptr, 0,
-                        c->pos_emb, c->Np, Dv, st));
+    const bool clip = d.v_kind == AHA_VISION_CLIP;
+    const int Dv = d.v_hidden, T = c->Tt, rows = n * T, vhd = Dv / d.v_heads;
+    HIPCHK(c, aha_im2col_norm(frames, n, d.image_size, d.patch_size, c->Kp, c->px_mean, c->px_std, c->v_a0, st));
+    if (!clip) {
+        HIPCHK(c, tile_gemm(c->v_a0, c->Kp, n * c->Np, c->patch_w, c->Kp, Dv, c->Kp, c->v_x, Dv, c->patch_b, ACT_NONE, nullptr, 0,
+                            c->pos_emb, c->Np, Dv, st));
+    } else {
+        // CLIP (transformers modeling_clip.py, CLIPVisionEmbeddings + pre_layrnorm): bias-free patch conv, class token, positions,
+        // then a LayerNorm over every token before layer 0.  The class token is row Np of each frame's T = Np + 1 rows.
+        HIPCHK(c, tile_gemm(c->v_a0, c->Kp, n * c->Np, c->patch_w, c->Kp, Dv, c->Kp, c->v_patch, Dv, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, aha_clip_assemble(c->v_patch, c->cls_emb, c->pos_emb, c->v_h, n, c->Np, Dv, st));
+        HIPCHK(c, aha_layernorm(c->v_h, Dv, c->pre_ln_w, c->pre_ln_b, c->v_x, Dv, rows, Dv, d.v_ln_eps, st));
+    }
+    const int act = clip ? ACT_QUICK_GELU : ACT_GELU_TANH;
     for (int l = 0; l < d.v_layers; ++l) {
         const VLayerW& w = c->V[l];
         HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
         HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
         AttnArgs a;
         memset(&a, 0, sizeof(a));
-        a.q = c->v_qkv; a.q_bs = (long)c->Np * 3 * Dv; a.ldq = 3 * Dv;
-        a.k = c->v_qkv + Dv; a.v = c->v_qkv + 2 * Dv; a.kv_bs = (long)c->Np * 3 * Dv; a.ldk = 3 * Dv;
-        a.out = c->v_attn; a.o_bs = (long)c->Np * Dv; a.ldo = Dv;
-        a.T = c->Np; a.G = 1; a.Hkv = d.v_heads; a.Lk = c->Np;
-        a.split_len = round_up(c->Np, 64); a.n_splits = 1;
+        a.q = c->v_qkv; a.q_bs = (long)T * 3 * Dv; a.ldq = 3 * Dv;
+        a.k = c->v_qkv + Dv; a.v = c->v_qkv + 2 * Dv; a.kv_bs = (long)T * 3 * Dv; a.ldk = 3 * Dv;
+        a.out = c->v_attn; a.o_bs = (long)T * Dv; a.ldo = Dv;
+        a.T = T; a.G = 1; a.Hkv = d.v_heads; a.Lk = T;
+        a.split_len = round_up(T, 64); a.n_splits = 1;
         a.scale = 1.0f / sqrtf((float)vhd);
         HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
         HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
         HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, w.b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, w.b1, act, nullptr, 0, nullptr, 0, 0, st));
         HIPCHK(c, tile_gemm(c->v_f, c->Fp, rows, w.w2, c->Fp, Dv, c->Fp, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
     }
     return 0;
@@ -697,13 +730,15 @@ extern "C" int aha_frame_ingest(aha_ctx* c, const uint8_t* src, int height, int 
 extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* out_embeds, aha_hip_stream st_) {
     int rc = vit_check(c, frames, out_embeds, n);
     if (rc || n <= 0) return rc;
+    if (c->d.v_kind != AHA_VISION_SIGLIP)
+        return fail(c, AHA_E_INVAL, "aha_vit_encode is the LLaVA SigLIP path; a CLIP tower is served by aha_vit_encode_pooled_first");
     hipStream_t st = (hipStream_t)st_;
     const aha_model_desc& d = c->d;
     const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
     HIPCHK(c, tile_gemm(c->v_x, Dv, rows, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, rows, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
-    HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, st));
+    HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, 0, st));
     return 0;
 }
 
@@ -714,14 +749,22 @@ extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, in
                                            aha_hip_stream st_) {
     int rc = vit_check(c, frames, out_embeds, n);
     if (rc || n <= 0) return rc;
-    if (!c->post_ln_w) return fail(c, AHA_E_NOENT, "vision.post_layernorm.{weight,bias} were not loaded");
+    const bool clip = c->d.v_kind == AHA_VISION_CLIP;
+    if (!clip && !c->post_ln_w) return fail(c, AHA_E_NOENT, "vision.post_layernorm.{weight,bias} were not loaded");
     if (pooled <= 0 || pooled > c->grid) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid");
     hipStream_t st = (hipStream_t)st_;
     const aha_model_desc& d = c->d;
-    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden, prow = n * pooled * pooled;
+    const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden, prow = n * pooled * pooled;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
-    HIPCHK(c, aha_layernorm(c->v_x, Dv, c->post_ln_w, c->post_ln_b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-    HIPCHK(c, aha_pool(c->v_h, c->v_attn, n, c->grid, pooled, Dv, 0, 3, st));
+    if (clip) {
+        // _clip_vision_encode (models/vision_live.py:34-49): last_hidden_state is the encoder output (transformers applies
+        // post_layernorm to the pooled class token only); the class token (last row of each frame here) is dropped by pooling
+        // over the first Np rows of each frame's Tt.
+        HIPCHK(c, aha_pool(c->v_x, c->v_attn, n, c->grid, pooled, Dv, 0, 3, c->Tt, st));
+    } else {
+        HIPCHK(c, aha_layernorm(c->v_x, Dv, c->post_ln_w, c->post_ln_b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+        HIPCHK(c, aha_pool(c->v_h, c->v_attn, n, c->grid, pooled, Dv, 0, 3, 0, st));
+    }
     HIPCHK(c, tile_gemm(c->v_attn, Dv, prow, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, prow, c->p2w, H, H, H, (bf16*)out_embeds, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
     return 0;
@@ -729,7 +772,8 @@ extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, in
 
 extern "C" int aha_vit_last_tower_output(aha_ctx* c, int n_frames, void* out, aha_hip_stream st) {
     if (!c || !out || n_frames <= 0 || n_frames > c->d.max_vit_frames) return AHA_E_INVAL;
-    HIPCHK(c, hipMemcpyAsync(out, c->v_x, (size_t)n_frames * c->Np * c->d.v_hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    // rows per frame: Np (SigLIP) or Np + 1 with the class token as the LAST row (CLIP)
+    HIPCHK(c, hipMemcpyAsync(out, c->v_x, (size_t)n_frames * c->Tt * c->d.v_hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
     return 0;
 }
 

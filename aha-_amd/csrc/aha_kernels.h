@@ -17,7 +17,7 @@ struct GemmWsArgs {
     int N;                           // valid output columns (for store guards)
 };
 
-enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2 };
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_QUICK_GELU = 3 };   // 3: CLIP, x * sigmoid(1.702 x), three bf16 roundings
 
 struct GemmTileArgs {
     const bf16* A; int lda; int M;
@@ -98,9 +98,10 @@ hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st);
 hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D, hipStream_t st);
 hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H, float* scores, float* raw, const int* poison, hipStream_t st);
-hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st);
+hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, const float* mean3, const float* std3, bf16* out, hipStream_t st);
+hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* pos, bf16* x, int n, int Np, int Dv, hipStream_t st);
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
-hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st);
+hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st);
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);
 hipError_t aha_ingest_launch(const IngestArgs* a, int method, hipStream_t st);

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void heads_kernel(const bf16* __restrict__ xn,
 // ---------------------------------------------------------------------------------------------
 // uint8 frames [N,3,S,S] -> normalised bf16 im2col rows [N*Np][Kp], column = c*P*P + iy*P + ix,
 // value = bf16((u8/255 - .5)/.5)  (preprocess fused into the patch gather; vision_live.py:11-13)
-__global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, int S, int P, int grid, int Kp,
+struct PixelNorm { float mean[3], std[3]; };
+__global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, int S, int P, int grid, int Kp, PixelNorm pn,
                                    bf16* __restrict__ out) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int kch = Kp >> 3;
@@ -247,7 +248,7 @@ __global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, in
         if (k < K) {
             const int c = k / PP, rem = k % PP, iy = rem / P, ix = rem % P;
             const uint8_t u = frames[(((long)n * 3 + c) * S + (py * P + iy)) * S + (px * P + ix)];
-            v = ((float)u * 0.00392156862745098f - 0.5f) / 0.5f;
+            v = ((float)u * 0.00392156862745098f - pn.mean[c]) / pn.std[c];   // normalize(frames * 1/255, mean, std) in fp32
         }
         o[e] = f2bf(v);
     }
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
 // post_projector_pooling (video_head_live_llava_qwen.py:117-136): [N, g, g, H] -> [N, go, go, H].
 // mode 0 = bilinear (align_corners=False), 1 = average (stride x stride), 2 = max.
 __global__ void pool_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int g, int go, int H,
-                            int stride, int mode) {
+                            int stride, int mode, int frame_rows) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int hch = H >> 3;
     const long total = (long)N * go * go * hch;
@@ -308,7 +309,7 @@ __global__ void pool_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
     const int hc = (int)(gid % hch);
     const long cell = gid / hch;
     const int ox = (int)(cell % go), oy = (int)((cell / go) % go), n = (int)(cell / ((long)go * go));
-    const bf16* base = in + (long)n * g * g * H + hc * 8;
+    const bf16* base = in + (long)n * frame_rows * H + hc * 8;       // frame_rows >= g*g (CLIP: a class-token row follows the patches)
     float acc[8];
     if (mode == 0) {
         const float sc = (float)g / (float)go;
@@ -440,10 +441,37 @@ hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int c
     hipLaunchKernelGGL(heads_kernel, dim3(count), dim3(256), 0, st, xn, ldx, row_first, row_step, heads_w, H, scores, raw, poison);
     return hipGetLastError();
 }
-hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, bf16* out, hipStream_t st) {
+hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, const float* mean3, const float* std3, bf16* out,
+                           hipStream_t st) {
     const int grid = S / P;
     const long total = (long)N * grid * grid * (Kp >> 3);
-    hipLaunchKernelGGL(im2col_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, N, S, P, grid, Kp, out);
+    PixelNorm pn;
+    for (int c = 0; c < 3; ++c) { pn.mean[c] = mean3[c]; pn.std[c] = std3[c]; }
+    hipLaunchKernelGGL(im2col_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, N, S, P, grid, Kp, pn, out);
+    return hipGetLastError();
+}
+
+// CLIP embeddings (CLIPVisionEmbeddings): x = cat([class_embedding, patches]) + position_embedding, one bf16 add per element.
+// Internal row order per frame: the Np patch tokens first, the class token LAST (the tower has no causal structure, so the order
+// is free as long as every token carries its own position row; `pos` is already stored in that order).
+__global__ void clip_assemble_kernel(const bf16* __restrict__ patches, const bf16* __restrict__ cls, const bf16* __restrict__ pos,
+                                     bf16* __restrict__ x, int n, int Np, int Dv) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dch = Dv >> 3, T = Np + 1;
+    if (gid >= (long)n * T * dch) return;
+    const int c = (int)(gid % dch) * 8;
+    const long row = gid / dch;
+    const int f = (int)(row / T), t = (int)(row % T);
+    const bf16x8 a = t < Np ? *reinterpret_cast<const bf16x8*>(patches + ((long)f * Np + t) * Dv + c) : *reinterpret_cast<const bf16x8*>(cls + c);
+    const bf16x8 p = *reinterpret_cast<const bf16x8*>(pos + (long)t * Dv + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(a[e]) + bf2f(p[e]));
+    *reinterpret_cast<bf16x8*>(x + row * Dv + c) = o;
+}
+hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* pos, bf16* x, int n, int Np, int Dv, hipStream_t st) {
+    const long total = (long)n * (Np + 1) * (Dv >> 3);
+    hipLaunchKernelGGL(clip_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, patches, cls, pos, x, n, Np, Dv);
     return hipGetLastError();
 }
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
@@ -452,9 +480,10 @@ hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, b
     hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, x, ldx, w, b, out, ldo, M, D, eps);
     return hipGetLastError();
 }
-hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, hipStream_t st) {
+hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st) {
     const long total = (long)N * go * go * (H >> 3);
-    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, N, g, go, H, stride, mode);
+    hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, N, g, go, H, stride, mode,
+                       frame_rows > 0 ? frame_rows : g * g);
     return hipGetLastError();
 }
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st) {

@@ -21,6 +21,12 @@ static __device__ __forceinline__ float gelu_tanh_f(float x) {
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 static __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// transformers QuickGELUActivation on bf16 tensors: input * sigmoid(1.702 * input), each op rounded to bf16
+static __device__ __forceinline__ float quick_gelu_bf16(float x) {
+    const float t = rbf(1.702f * x);
+    const float s = rbf(1.0f / (1.0f + __expf(-t)));
+    return x * s;                                     // the caller rounds the product
+}
 
 // WT = 16x16 MFMA tiles per wave per dimension: WT = 4 -> 128x128 block tile (throughput shapes),
 // WT = 2 -> 64x64 block tile (M <= ~1k rows: single-frame latency; 4x the workgroups).
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
                 float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));            // Linear output (bf16)
                 if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
                 else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
                 if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
                 if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
                 o[e] = f2bf(x);
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tile_dma_kernel(G
                 float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));
                 if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
                 else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
                 if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
                 if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
                 o[e] = f2bf(x);
@@ -484,6 +492,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
                 float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));
                 if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
                 else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
                 if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
                 if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
                 o[e] = f2bf(x);
@@ -679,6 +688,7 @@ __global__ __launch_bounds__(512) void gemm_tile_256_kernel(GemmTileArgs g) {
                 float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));
                 if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
                 else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
                 if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
                 if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
                 o[e] = f2bf(x);

@@ -21,7 +21,7 @@ class ModelDesc(C.Structure):
         ("head_dim", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32),
         ("rope_theta", C.c_float), ("rms_eps", C.c_float),
         ("max_positions", C.c_int32), ("pool_stride", C.c_int32), ("pool_mode", C.c_int32),
-        ("max_step_tokens", C.c_int32), ("max_vit_frames", C.c_int32),
+        ("max_step_tokens", C.c_int32), ("max_vit_frames", C.c_int32), ("v_kind", C.c_int32),
     ]
 
 

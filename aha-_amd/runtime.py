@@ -111,7 +111,8 @@ class Runtime:
             kv_heads=lm.num_key_value_heads, head_dim=lm.head_dim, inter=lm.intermediate_size, vocab=lm.vocab_size,
             rope_theta=lm.rope_theta, rms_eps=lm.rms_norm_eps,
             max_positions=max_positions or lm.max_position_embeddings, pool_stride=cfg.video_pooling_stride,
-            pool_mode=_POOL_MODE[cfg.mm_spatial_pool_mode], max_step_tokens=max_step_tokens, max_vit_frames=max_vit_frames)
+            pool_mode=_POOL_MODE[cfg.mm_spatial_pool_mode], max_step_tokens=max_step_tokens, max_vit_frames=max_vit_frames,
+            v_kind={"siglip": 0, "clip": 1}[v.kind])
         ctx = C.c_void_p()
         rc = self.lib.aha_ctx_create(C.byref(self.desc), self.device.index or 0, C.byref(ctx))
         self.ctx = ctx if ctx.value else None
@@ -233,8 +234,9 @@ class Runtime:
         return out
 
     def tower_output(self, n_frames: int) -> torch.Tensor:
-        """bf16 [n*Np, Dv] tower output of the last visual_embed call (test tap; copies)."""
-        rows, dv = n_frames * self.cfg.vision.num_patches, self.cfg.vision.hidden_size
+        """bf16 [n*Tt, Dv] tower output of the last encode (test tap; copies).  Tt = Np, or Np + 1 for a CLIP tower, whose class
+        token is the LAST row of each frame's block (the oracle / transformers keep it first)."""
+        rows, dv = n_frames * (self.cfg.vision.num_patches + (1 if self.cfg.vision.kind == "clip" else 0)), self.cfg.vision.hidden_size
         out = torch.empty((rows, dv), dtype=torch.bfloat16, device=self.device)
         self._chk(self.lib.aha_vit_last_tower_output(self.ctx, n_frames, out.data_ptr(), _cur_stream()))
         return out

@@ -22,8 +22,14 @@ def tensor_specs(cfg: LiveConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
     v, lm = cfg.vision, cfg.lm
     Dv, H = v.hidden_size, lm.hidden_size
     yield "vision.embeddings.patch_embedding.weight", (Dv, 3, v.patch_size, v.patch_size), "w"
-    yield "vision.embeddings.patch_embedding.bias", (Dv,), "b"
-    yield "vision.embeddings.position_embedding.weight", (v.num_patches, Dv), "emb"
+    if v.kind == "clip":                 # CLIPVisionEmbeddings: bias-free patch conv, class token, Np + 1 positions, pre-LN
+        yield "vision.embeddings.class_embedding", (Dv,), "emb"
+        yield "vision.embeddings.position_embedding.weight", (v.num_patches + 1, Dv), "emb"
+        yield "vision.pre_layrnorm.weight", (Dv,), "norm_w"
+        yield "vision.pre_layrnorm.bias", (Dv,), "norm_b"
+    else:
+        yield "vision.embeddings.patch_embedding.bias", (Dv,), "b"
+        yield "vision.embeddings.position_embedding.weight", (v.num_patches, Dv), "emb"
     for i in range(v.num_hidden_layers):
         p = f"vision.encoder.layers.{i}."
         yield p + "layer_norm1.weight", (Dv,), "norm_w"

@@ -36,7 +36,10 @@ typedef struct aha_model_desc {
     int32_t pool_stride, pool_mode;           /* pool_mode: 0 bilinear, 1 average, 2 max */
     int32_t max_step_tokens;                  /* largest B*T of one aha_lm_step */
     int32_t max_vit_frames;                   /* largest n_frames of one aha_vit_encode */
+    int32_t v_kind;                           /* AHA_VISION_SIGLIP (0) or AHA_VISION_CLIP (1: class token, pre_layrnorm, quick_gelu,
+                                                 OpenAI mean/std; serves models/vision_live.py:34-54 via aha_vit_encode_pooled_first) */
 } aha_model_desc;
+enum { AHA_VISION_SIGLIP = 0, AHA_VISION_CLIP = 1 };
 
 /* One named checkpoint tensor (bf16, row-major, device memory).  Names are the checkpoint's:
  * "model.layers.N.self_attn.q_proj.weight", "mm_projector.0.weight", "informative_head.weight",
@@ -94,7 +97,9 @@ int aha_vit_encode(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* o
 /* The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode, frame_token_cls=False) followed
  * by LiveMixin's connector (models/modeling_live.py:31-37): tower -> post_layernorm (last_hidden_state) ->
  * adaptive_avg_pool2d to pooled x pooled (frame_token_pooled, models/arguments_live.py:21) -> mm_projector.
- * Needs "vision.post_layernorm.{weight,bias}".  out_embeds: bf16 [n*pooled*pooled][hidden] */
+ * Needs "vision.post_layernorm.{weight,bias}".  With v_kind = AHA_VISION_CLIP it is _clip_vision_encode (:34-54):
+ * OpenAI mean/std, CLIP tower (class token, pre_layrnorm, quick_gelu), last_hidden_state WITHOUT post-layernorm,
+ * class token dropped, same pooling and connector.  out_embeds: bf16 [n*pooled*pooled][hidden] */
 int aha_vit_encode_pooled_first(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, int pooled, void* out_embeds,
                                 aha_hip_stream st);
 /* parity-test tap: copy the tower output of the last encode, bf16 [n_frames*Np][v_hidden] */

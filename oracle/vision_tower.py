@@ -9,6 +9,9 @@ CPU restatement of the vision half of the reference's per-frame path:
   post_projector_pooling                video_head_live_llava_qwen.py:117-136
   visual_embed                          models/modeling_live.py:31-37
   _siglip_vision_encode (dead-code spec) models/vision_live.py:11-31
+  _clip_vision_encode (dead-code spec)   models/vision_live.py:34-54  (CLIP tower restated from the local
+                                        transformers copy, models/clip/modeling_clip.py: CLIPVisionEmbeddings,
+                                        CLIPEncoderLayer, CLIPVisionTransformer; pinned in tests/test_oracle_models.py)
 
 LLaVA-NeXT is absent from /root/reference (empty submodule dir), so the tower arithmetic
 is restated from the published SigLIP architecture as implemented by the local
@@ -128,4 +131,61 @@ def vision_live_encode(ov: "OracleVision", frames_u8: torch.Tensor, post_ln_w: t
     sp = F.adaptive_avg_pool2d(x.reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))
     sp = sp.flatten(2, 3).permute(0, 2, 1)
     y = ov.connector(sp)
+    return y.reshape(-1, y.shape[-1])
+
+
+# ---- CLIP (models/vision_live.py:34-54) -----------------------------------------------------------------
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # transformers.utils.constants
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def preprocess_clip(frames_u8: torch.Tensor, dtype) -> torch.Tensor:
+    """normalize(frames * 1/255, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD) in fp32 (vision_live.py:34-36), then the working dtype"""
+    x = frames_u8.to(torch.float32) * 0.00392156862745098
+    mean = torch.tensor(OPENAI_CLIP_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(OPENAI_CLIP_STD, dtype=torch.float32).view(1, 3, 1, 1)
+    return ((x - mean) / std).to(dtype)
+
+
+class OracleCLIPVision(OracleVision):
+    """CLIPVisionTransformer up to `last_hidden_state` (the encoder output, WITHOUT post_layernorm, which transformers
+    applies to the pooled class token only): bias-free patch conv, class embedding prepended, learned positions,
+    pre_layrnorm, pre-LN encoder layers with quick_gelu (x * sigmoid(1.702 x)).  Token 0 is the class token."""
+
+    @torch.no_grad()
+    def tower(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        v, w = self.v, self.w
+        x = F.conv2d(pixel_values, w["vision.embeddings.patch_embedding.weight"], None, stride=v.patch_size)
+        x = x.flatten(2).transpose(1, 2)
+        cls = w["vision.embeddings.class_embedding"].expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1) + w["vision.embeddings.position_embedding.weight"][None]
+        N, T, Dv = x.shape
+        x = F.layer_norm(x, (Dv,), w["vision.pre_layrnorm.weight"], w["vision.pre_layrnorm.bias"], v.layer_norm_eps)
+        nh, hd = v.num_attention_heads, v.head_dim
+        for i in range(v.num_hidden_layers):
+            p = f"vision.encoder.layers.{i}."
+            r = x
+            h = F.layer_norm(x, (Dv,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], v.layer_norm_eps)
+            q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(N, T, nh, hd).transpose(1, 2)
+            k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(N, T, nh, hd).transpose(1, 2)
+            vv = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(N, T, nh, hd).transpose(1, 2)
+            o = F.scaled_dot_product_attention(q, k, vv, scale=hd ** -0.5).transpose(1, 2).reshape(N, T, Dv)
+            x = r + F.linear(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+            r = x
+            h = F.layer_norm(x, (Dv,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], v.layer_norm_eps)
+            h = F.linear(h, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
+            h = h * torch.sigmoid(1.702 * h)                       # QuickGELUActivation
+            x = r + F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+        return x
+
+
+def clip_live_encode(ov: "OracleCLIPVision", frames_u8: torch.Tensor, frame_token_pooled=(7, 7)) -> torch.Tensor:
+    """models/vision_live.py:34-54 (_clip_vision_encode, frame_token_cls=False) then LiveMixin.visual_embed's connector:
+    normalize with the OpenAI CLIP constants -> last_hidden_state -> drop the class token -> adaptive_avg_pool2d over the
+    patch grid -> connector.  Returns [N*ph*pw, H]."""
+    x = ov.tower(preprocess_clip(frames_u8, ov.dtype))
+    n, t, d = x.shape
+    s = int(math.sqrt(t))                                          # the reference takes sqrt of Np + 1 and truncates
+    sp = F.adaptive_avg_pool2d(x[:, 1:].reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))
+    y = ov.connector(sp.flatten(2, 3).permute(0, 2, 1))
     return y.reshape(-1, y.shape[-1])

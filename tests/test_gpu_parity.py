@@ -743,3 +743,43 @@ def test_graph_replay_of_frozen_static_steps_is_bit_identical(tiny128, bench_rt)
             st.close()
         rt.set_tuning("use_graph", 1)
         assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_clip_vision_encode_contract():
+    """The CLIP half of models/vision_live.py (_clip_vision_encode): OpenAI mean/std, class token, pre_layrnorm, quick_gelu,
+    last_hidden_state without post-layernorm, class token dropped, adaptive average pool, connector - against the oracle
+    (itself pinned to transformers CLIPVisionModel in tests/test_oracle_models.py).  Tiny model for the numbers, then a
+    CLIP-L/14@336-shaped tower (577 tokens per frame: ragged last query tile) for shapes and finiteness."""
+    import dataclasses
+    from aha_amd.config import LiveConfig, LMConfig, VisionConfig
+    from aha_amd.runtime import AhaError
+    from oracle.vision_tower import OracleCLIPVision, clip_live_encode, preprocess_clip
+    base = preset("tiny128")
+    cfg = dataclasses.replace(base, vision=dataclasses.replace(base.vision, kind="clip", layer_norm_eps=1e-5), name="tiny_clip")
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=4, max_positions=1024)
+    fr = make_frames(3, cfg.vision.image_size, seed=17)
+    ov = OracleCLIPVision(cfg, w, torch.bfloat16)
+    want = clip_live_encode(ov, fr, (3, 3)).float()
+    got = rt.vision_live_embed(fr.cuda(), pooled=3).float().cpu()
+    assert got.shape == want.shape == (3 * 9, cfg.lm.hidden_size)
+    assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
+    tower = rt.tower_output(3).float().cpu().view(3, cfg.vision.num_patches + 1, -1)
+    ref = ov.tower(preprocess_clip(fr, torch.bfloat16)).float()            # class token first
+    assert (tower[:, :-1] - ref[:, 1:]).abs().max().item() <= 0.03 * max(1.0, ref.abs().max().item())   # patches
+    assert (tower[:, -1] - ref[:, 0]).abs().max().item() <= 0.03 * max(1.0, ref.abs().max().item())      # class token (kept last here)
+    with pytest.raises(AhaError):
+        rt.visual_embed(fr.cuda())                          # the LLaVA path is SigLIP-only
+    rt.close()
+    big = LiveConfig(vision=VisionConfig(image_size=336, patch_size=14, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
+                                         intermediate_size=4096, layer_norm_eps=1e-5, kind="clip"),
+                     lm=LMConfig(hidden_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                                 intermediate_size=512, vocab_size=512), name="clipL")
+    wb = make_weights(big, dtype=torch.bfloat16, jitter=True)
+    rtb = _rt(big, wb, max_step_tokens=64, max_vit_frames=2, max_positions=1024)
+    frb = make_frames(2, 336, seed=18)
+    gb = rtb.vision_live_embed(frb.cuda(), pooled=7).float().cpu()
+    wantb = clip_live_encode(OracleCLIPVision(big, wb, torch.bfloat16), frb, (7, 7)).float()
+    assert gb.shape == (2 * 49, 256) and torch.isfinite(gb).all()
+    assert (gb - wantb).abs().max().item() <= 0.03 * max(1.0, wantb.abs().max().item())
+    rtb.close()

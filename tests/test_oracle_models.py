@@ -85,6 +85,46 @@ def test_vision_matches_golden_and_transformers():
         assert (hs.float() - yo.float()).abs().max().item() <= (2e-5 if dt == torch.float32 else 0.04)
 
 
+def test_clip_tower_matches_transformers_and_encode_contract():
+    """The CLIP half of models/vision_live.py (_clip_vision_encode): the oracle's CLIP tower against local transformers
+    CLIPVisionModel.last_hidden_state (class token, pre_layrnorm, quick_gelu, no post-layernorm), and the encode contract
+    (OpenAI mean/std, class token dropped, adaptive average pool) against the same calls on the transformers output."""
+    import dataclasses
+    import math
+    import torch.nn.functional as F
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    from oracle.vision_tower import OracleCLIPVision, clip_live_encode, preprocess_clip
+    base = preset("tiny")
+    cfg = dataclasses.replace(base, vision=dataclasses.replace(base.vision, kind="clip", layer_norm_eps=1e-5), name="tiny_clip")
+    v = cfg.vision
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    assert w["vision.embeddings.position_embedding.weight"].shape == (v.num_patches + 1, v.hidden_size)
+    fr = make_frames(2, v.image_size, seed=3)
+    vc = CLIPVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size, num_hidden_layers=v.num_hidden_layers,
+                          num_attention_heads=v.num_attention_heads, image_size=v.image_size, patch_size=v.patch_size,
+                          layer_norm_eps=v.layer_norm_eps, hidden_act="quick_gelu", attn_implementation="sdpa")
+    for dt in (torch.float32, torch.bfloat16):
+        vm = CLIPVisionModel(vc).to(dt).eval()
+        sd = {k[len("vision."):]: t.to(dt) for k, t in w.items() if k.startswith("vision.")}
+        target = vm.vision_model if hasattr(vm, "vision_model") else vm
+        missing = target.load_state_dict(sd, strict=False)
+        assert not [k for k in missing.missing_keys if "post_layernorm" not in k and "position_ids" not in k], missing.missing_keys
+        px = preprocess_clip(fr, dt)
+        with torch.no_grad():
+            hs = vm(pixel_values=px).last_hidden_state
+        ov = OracleCLIPVision(cfg, w, dt)
+        yo = ov.tower(px)
+        assert hs.shape == yo.shape == (2, v.num_patches + 1, v.hidden_size)
+        assert (hs.float() - yo.float()).abs().max().item() <= (2e-5 if dt == torch.float32 else 0.06)
+        if dt == torch.float32:
+            # the reference's own post-processing of last_hidden_state (vision_live.py:40-49) + the connector
+            s_ = int(math.sqrt(hs.shape[1]))
+            sp = F.adaptive_avg_pool2d(hs[:, 1:].reshape(2, s_, s_, -1).permute(0, 3, 1, 2), (2, 2)).flatten(2, 3).permute(0, 2, 1)
+            want = ov.connector(sp).reshape(-1, cfg.lm.hidden_size)
+            got = clip_live_encode(ov, fr, (2, 2))
+            assert got.shape == want.shape and (got - want).abs().max().item() <= 2e-5
+
+
 def test_visual_embed_shapes_and_pool():
     for name, tf in (("tiny", 4), ("tiny128", 9)):
         cfg = preset(name)
