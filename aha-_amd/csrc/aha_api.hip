@@ -730,15 +730,15 @@ extern "C" int aha_frame_ingest(aha_ctx* c, const uint8_t* src, int height, int 
 extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* out_embeds, aha_hip_stream st_) {
     int rc = vit_check(c, frames, out_embeds, n);
     if (rc || n <= 0) return rc;
-    if (c->d.v_kind != AHA_VISION_SIGLIP)
-        return fail(c, AHA_E_INVAL, "aha_vit_encode is the LLaVA SigLIP path; a CLIP tower is served by aha_vit_encode_pooled_first");
     hipStream_t st = (hipStream_t)st_;
     const aha_model_desc& d = c->d;
-    const int Dv = d.v_hidden, rows = n * c->Np, H = d.hidden;
+    // With a CLIP tower (LLaVA's select_feature = 'patch') the projector also runs over the class-token rows (1 in Np + 1,
+    // cheaper than compacting) and the pooling reads the Np patch rows of each frame's Tt.
+    const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
     HIPCHK(c, tile_gemm(c->v_x, Dv, rows, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, rows, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
-    HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, 0, st));
+    HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, c->Tt, st));
     return 0;
 }
 

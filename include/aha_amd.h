@@ -92,7 +92,8 @@ const char* aha_last_error(aha_ctx* ctx);
 /* ---- vision: LiveMixin.visual_embed (models/modeling_live.py:31-37) on raw uint8 frames, i.e.
  * image_processor.preprocess (test/inference.py:176) + vision_tower + mm_projector +
  * post_projector_pooling (video_head_live_llava_qwen.py:107-136) ----------------------------- */
-/* frames_u8: [n,3,S,S] uint8 RGB; out_embeds: bf16 [n*Tf][hidden] */
+/* frames_u8: [n,3,S,S] uint8 RGB; out_embeds: bf16 [n*Tf][hidden].  With v_kind = AHA_VISION_CLIP: CLIP tower, patch features
+ * only (the class token is dropped, LLaVA's select_feature = 'patch'), OpenAI mean/std. */
 int aha_vit_encode(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* out_embeds, aha_hip_stream st);
 /* The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode, frame_token_cls=False) followed
  * by LiveMixin's connector (models/modeling_live.py:31-37): tower -> post_layernorm (last_hidden_state) ->

@@ -179,6 +179,14 @@ class OracleCLIPVision(OracleVision):
         return x
 
 
+def clip_visual_embed(ov: "OracleCLIPVision", frames_u8: torch.Tensor) -> torch.Tensor:
+    """LiveMixin.visual_embed with a CLIP tower the way LLaVA wires one (select_feature = 'patch': class token dropped,
+    CLIPImageProcessor's OpenAI mean/std): tower -> patch features -> connector -> post_projector_pooling."""
+    x = ov.tower(preprocess_clip(frames_u8, ov.dtype))[:, 1:]
+    x = ov.post_projector_pooling(ov.connector(x))
+    return x.reshape(-1, x.shape[-1])
+
+
 def clip_live_encode(ov: "OracleCLIPVision", frames_u8: torch.Tensor, frame_token_pooled=(7, 7)) -> torch.Tensor:
     """models/vision_live.py:34-54 (_clip_vision_encode, frame_token_cls=False) then LiveMixin.visual_embed's connector:
     normalize with the OpenAI CLIP constants -> last_hidden_state -> drop the class token -> adaptive_avg_pool2d over the

@@ -752,8 +752,7 @@ def test_clip_vision_encode_contract():
     CLIP-L/14@336-shaped tower (577 tokens per frame: ragged last query tile) for shapes and finiteness."""
     import dataclasses
     from aha_amd.config import LiveConfig, LMConfig, VisionConfig
-    from aha_amd.runtime import AhaError
-    from oracle.vision_tower import OracleCLIPVision, clip_live_encode, preprocess_clip
+    from oracle.vision_tower import OracleCLIPVision, clip_live_encode, clip_visual_embed, preprocess_clip
     base = preset("tiny128")
     cfg = dataclasses.replace(base, vision=dataclasses.replace(base.vision, kind="clip", layer_norm_eps=1e-5), name="tiny_clip")
     w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
@@ -768,8 +767,9 @@ def test_clip_vision_encode_contract():
     ref = ov.tower(preprocess_clip(fr, torch.bfloat16)).float()            # class token first
     assert (tower[:, :-1] - ref[:, 1:]).abs().max().item() <= 0.03 * max(1.0, ref.abs().max().item())   # patches
     assert (tower[:, -1] - ref[:, 0]).abs().max().item() <= 0.03 * max(1.0, ref.abs().max().item())      # class token (kept last here)
-    with pytest.raises(AhaError):
-        rt.visual_embed(fr.cuda())                          # the LLaVA path is SigLIP-only
+    emb = rt.visual_embed(fr.cuda()).float().cpu()            # LLaVA-style path with the CLIP tower: patch features only
+    want_e = clip_visual_embed(ov, fr).float()
+    assert emb.shape == want_e.shape and (emb - want_e).abs().max().item() <= 0.03 * max(1.0, want_e.abs().max().item())
     rt.close()
     big = LiveConfig(vision=VisionConfig(image_size=336, patch_size=14, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16,
                                          intermediate_size=4096, layer_norm_eps=1e-5, kind="clip"),
