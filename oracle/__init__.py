@@ -10,5 +10,5 @@ model code is not importable here (absent llava/peft/deepspeed/wandb), so the re
 is pinned by (1) the local transformers Qwen2Model / SiglipVisionModel on seeded configs,
 (2) the reference's own cache classes test/{sink,sliding_window,static}_cache.py imported
 from /root/reference, and (3) the golden fixtures under tests/golden/ generated from (1)
-and (2) by tools/make_golden.py.  See DESIGN.md "Oracle".
+and (2) by tests/make_golden.py.  See DESIGN.md "Oracle".
 """

@@ -11,7 +11,7 @@ Two paths exist in the reference and they use different resamplers:
   -> horizontal pass to a uint8 image -> vertical pass, each `clip8((1 << 21) + sum(pixel * k) >> 22)`.
   PINNED: tests/test_frame_ingest.py compares it bit for bit with the Pillow installed here (12.2.0; the 8-bit
   resampler is unchanged since 10.4) on random images over many geometries, and tests/golden/frame_ingest.npz holds
-  Pillow-generated vectors for the GPU box (tools/make_golden.py).
+  Pillow-generated vectors for the GPU box (tests/make_golden.py).
 
 * benchmark path, `load_video_for_testing` / `load_video` (test/inference.py:538-562,
   test/live_infer_for_video.py:49-71): `cv2.resize(frame, (new_w, new_h))` (opencv-python==4.10.0.84,

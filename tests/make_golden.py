@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz.  Run in the authoring container only (needs
 /root/reference for the cache fixture and local transformers for the model fixtures):
 
-    python tools/make_golden.py
+    python tests/make_golden.py
 
 Fixtures are data (seeds, inputs, expected outputs), never reference source text:
   cache_policies.npz   outputs of the reference's own SinkCache / SlidingWindowCache /
@@ -21,7 +21,7 @@ from unittest import mock
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "golden")
 

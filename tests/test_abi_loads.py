@@ -35,10 +35,26 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
-    for f in ("bench.py",):
-        p = os.path.join(ROOT, f)
-        if os.path.exists(p):
-            pass  # bench.py may use the oracle only in its cpu_baseline leg (checked by review)
+    # developer tooling is not allowed to touch the oracle either (its users live under tests/)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+    # bench.py: only inside cpu_baseline(); __graft_entry__.py: only inside smoke()
+    import ast
+    for f, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(ROOT, f)).read())
+        for fn in ast.walk(tree):
+            if isinstance(fn, (ast.FunctionDef, ast.Module)):
+                for node in (fn.body if isinstance(fn, ast.Module) else ast.walk(fn)):
+                    names = []
+                    if isinstance(node, ast.ImportFrom) and node.module:
+                        names = [node.module]
+                    elif isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                        assert isinstance(fn, ast.FunctionDef) and fn.name == allowed, f"{f}: oracle imported outside {allowed}()"
 
 
 def test_runtime_refuses_to_run_without_gpu():

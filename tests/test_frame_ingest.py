@@ -9,7 +9,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import frame_ingest as fi  # noqa: E402
 from make_golden import INGEST_CASES, ingest_frame  # noqa: E402
 

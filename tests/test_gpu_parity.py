@@ -581,11 +581,11 @@ def test_vision_live_contract_pooled_first():
 # ---------------------------------------------------------------------------------------------------
 def test_frame_ingest_matches_pillow_golden_vectors(tiny, tiny128):
     """aha_frame_ingest (PIL-bicubic method) against canvases produced by Pillow's own Image.resize + ImageOps.expand
-    (tests/golden/frame_ingest.npz, generated by tools/make_golden.py): exact."""
+    (tests/golden/frame_ingest.npz, generated by tests/make_golden.py): exact."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "tools"))
+    sys.path.insert(0, os.path.join(root, "tests"))
     from make_golden import INGEST_CASES, ingest_frame
     gold = np.load(os.path.join(root, "tests", "golden", "frame_ingest.npz"))
     rts = {56: tiny[2], 84: tiny128[2]}

@@ -1,5 +1,5 @@
 """Pin oracle/cache_policies.py: (a) against the golden outputs of the reference's own cache
-classes (tests/golden/cache_policies.npz, made by tools/make_golden.py from
+classes (tests/golden/cache_policies.npz, made by tests/make_golden.py from
 /root/reference/test/{sink,sliding_window,static}_cache.py), (b) live against those classes
 when /root/reference is present."""
 import os

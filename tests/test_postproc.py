@@ -1,6 +1,6 @@
 """aha_amd.postproc against the reference's own metric functions (test/tvsum/tvsum_utils.py,
 test/hisum/hisum_eval.py: importable from /root/reference) - live when present, and through
-tests/golden/postproc.json (made by tools/make_golden.py from those functions)."""
+tests/golden/postproc.json (made by tests/make_golden.py from those functions)."""
 import json
 import os
 import sys
