@@ -55,8 +55,12 @@ struct aha_ctx {
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
     // HIP-graph replay of frozen TrulyStaticCache steps (tuning "use_graph"): cached executables keyed by the exact step
+    // device-resident step descriptor: written to a pinned ring slot and uploaded once per step (1 KB), so kernels take a
+    // constant pointer and a captured graph does not bake the per-step stream state in
+    StepDesc* sd_pin = nullptr; StepDesc* sd_dev = nullptr; int sd_slot = 0;
+    static constexpr int SD_SLOTS = 256;
     struct GraphEntry {
-        StepDesc sd; int B = 0, T = 0, epoch = 0, seen = 0; hipGraphExec_t exec = nullptr; bool failed = false;
+        int B = 0, T = 0, epoch = 0, n_splits = 0, split_len = 0, flags = 0, seen = 0; hipGraphExec_t exec = nullptr; bool failed = false;
         double wb = 0, fl = 0; int ev_used[8] = {0}; double gk_bytes[8] = {0};      // bookkeeping of the captured step
     };
     std::vector<GraphEntry> graphs;
@@ -179,6 +183,10 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     if ((rc = dalloc(c, &c->logits, (size_t)AHA_MAX_B * d->vocab))) return rc;
     if ((rc = dalloc(c, &c->heads_tmp, M * 4))) return rc;
 
+    // ---- device-resident step descriptor
+    if ((rc = dalloc(c, &c->sd_dev, 1))) return rc;
+    if (hipHostMalloc((void**)&c->sd_pin, sizeof(StepDesc) * aha_ctx::SD_SLOTS, hipHostMallocDefault) != hipSuccess)
+        return fail(c, AHA_E_NOMEM, "hipHostMalloc failed");
     // ---- graph replay state
     if ((rc = dalloc(c, &c->graph_scores, (size_t)AHA_MAX_B * 3))) return rc;
     if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, AHA_E_HIP, "hipStreamCreate failed");
@@ -215,6 +223,7 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     for (auto& g : c->graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    if (c->sd_pin) hipHostFree(c->sd_pin);
     for (void* p : c->allocs) hipFree(p);
     for (int k = 0; k < GK_COUNT; ++k)
         for (auto& pr : c->ev[k]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -892,19 +901,46 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         c->last_kv_bytes += (double)sd.s[b].len_after * d.layers * d.kv_heads * Dh * 2 * 2;
     }
     {
-        // streams sharing (W, sink) share the table; launch per group
+        // Upload this step's descriptor (pinned ring slot -> the one device copy; stream order keeps the previous step's
+        // kernels ahead of the overwrite; the ring is far deeper than the launches a HIP queue can hold).
+        StepDesc* slot = c->sd_pin + c->sd_slot;
+        c->sd_slot = (c->sd_slot + 1) % aha_ctx::SD_SLOTS;
+        *slot = sd;
+        HIPCHK(c, hipMemcpyAsync(c->sd_dev, slot, sizeof(StepDesc), hipMemcpyHostToDevice, st));
+        // streams sharing (W, sink) share the table; one launch per group, selected by a stream mask
         bool done[AHA_MAX_B] = {false};
         for (int b = 0; b < B; ++b) {
             if (done[b] || sd.s[b].n_rerot == 0) continue;
-            StepDesc g = sd;
+            unsigned mask = 0;
+            int nmax = 0;
             for (int b2 = 0; b2 < B; ++b2) {
                 const bool same = sd.s[b2].n_rerot > 0 && streams[b2]->W == streams[b]->W && streams[b2]->sink == streams[b]->sink;
-                if (same) done[b2] = true; else g.s[b2].n_rerot = 0;
+                if (same) {
+                    done[b2] = true;
+                    mask |= 1u << b2;
+                    nmax = sd.s[b2].n_rerot > nmax ? sd.s[b2].n_rerot : nmax;
+                }
             }
             auto tb = c->rerot[std::make_tuple(streams[b]->W, streams[b]->sink, T)];
-            HIPCHK(c, aha_sink_rerotate(&g, tb.first, tb.second, d.layers, d.kv_heads, Dh, st));
+            HIPCHK(c, aha_sink_rerotate(c->sd_dev, mask, B, nmax, tb.first, tb.second, d.layers, d.kv_heads, Dh, st));
         }
     }
+
+    // attention geometry (launch shape only: the kernels read the key counts from the device descriptor)
+    int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
+    int n_splits = ceil_div(max_lk, split_len);
+    if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
+    if (n_splits < 1) n_splits = 1;
+
+    // Every stream of the step a frozen TrulyStaticCache: the new tokens' K/V are neither stored nor read
+    // (test/static_cache.py:33-36).  By default the full q|k|v projection still runs, as in the reference (its K/V columns
+    // are dead work, but the headline streams what the reference streams).  Experiments: fuse_static = 2 projects only the
+    // q tiles (they come first in the packed weight; same split, bit-identical q; -0.7 % step time); fuse_static = 1 also
+    // builds Q inside the attention kernel instead of launching qkv_finish (measured slower).
+    bool all_static_frozen = true;
+    for (int b = 0; b < B; ++b) all_static_frozen = all_static_frozen && sd.s[b].write_base < 0;
+    const bool q_only = all_static_frozen && c->fuse_static != 0;
+    const bool frozen_all = all_static_frozen && c->fuse_static == 1;
 
     // Everything from the first RMSNorm to the heads, on stream `st`, scores to `scores_out`: run directly, or recorded
     // into a HIP graph (below).
@@ -912,21 +948,6 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[0].ln1, c->xn, H, M, H, d.rms_eps, st));
 
-        // attention geometry
-        int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
-        int n_splits = ceil_div(max_lk, split_len);
-        if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
-        if (n_splits < 1) n_splits = 1;
-
-        // Every stream of the step a frozen TrulyStaticCache: the new tokens' K/V are neither stored nor read
-        // (test/static_cache.py:33-36).  By default the full q|k|v projection still runs, as in the reference (its K/V columns
-        // are dead work, but the headline streams what the reference streams).  Experiments: fuse_static = 2 projects only the
-        // q tiles (they come first in the packed weight; same split, bit-identical q; -0.7 % step time); fuse_static = 1 also
-        // builds Q inside the attention kernel instead of launching qkv_finish (measured slower).
-        bool all_static_frozen = true;
-        for (int b = 0; b < B; ++b) all_static_frozen = all_static_frozen && sd.s[b].write_base < 0;
-        const bool q_only = all_static_frozen && c->fuse_static != 0;
-        const bool frozen_all = all_static_frozen && c->fuse_static == 1;
         int rc;
         for (int l = 0; l < d.layers; ++l) {
             const LayerW& w = c->L[l];
@@ -944,7 +965,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
                 qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
                 qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
-                HIPCHK(c, aha_qkv_finish(&qa, &sd, st));
+                HIPCHK(c, aha_qkv_finish(&qa, c->sd_dev, M, st));
             } else {
                 a.q_partial = c->partial; a.q_S = Sq; a.q_slab_stride = (long)M * nq_ld; a.q_ldp = nq_ld; a.q_bias = w.qkv_bias;
                 a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.n_pos = c->n_pos;
@@ -955,7 +976,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             a.part_o = c->part_o; a.part_ml = c->part_ml;
             a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
             a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
-            HIPCHK(c, aha_attention(&a, &sd, B, Dh, st));
+            HIPCHK(c, aha_attention(&a, c->sd_dev, B, Dh, st));
             // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
             const int So = pick_split(c, GK_O, w.o, M, 1);
             if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
@@ -992,7 +1013,6 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             ra.S = Sd;
             ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
             HIPCHK(c, aha_resid_norm(&ra, M, st));
-            c->last_flops += 4.0 * T * (double)max_lk * QD * B;
         }
         // ---- heads on the last token of every stream
         if (scores_out || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, scores_out, out_raw, c->bar_err, st));
@@ -1006,26 +1026,30 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     // ---- residual stream <- embeds
     HIPCHK(c, hipMemcpyAsync(c->h, embeds, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
 
-    // ---- HIP-graph replay.  After its first call a TrulyStaticCache stream's StreamStep never changes (frozen prefix, nothing
-    // stored; test/static_cache.py:26-36), so a step whose streams are all frozen is the SAME ~230 launches with the same
-    // kernel arguments every frame.  The host needs ~9 us per launch and falls behind the GPU in the run of short kernels
-    // (QKV -> finish -> attention -> O -> norm: measured 175 us of idle gaps per 3.2 ms step); replaying a captured graph
-    // removes that.  Keyed by the exact StepDesc + shapes + tuning epoch; captured on a private stream the second time a key is
-    // seen (every lazily set kernel attribute has been set by then); any failure falls back to direct launches for that key.
-    bool all_frozen = true;
-    for (int b = 0; b < B; ++b) all_frozen = all_frozen && sd.s[b].write_base < 0 && sd.s[b].n_rerot == 0;
-    if (c->use_graph && all_frozen && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp) {
+    // ---- HIP-graph replay.  A step is ~230 launches; the host needs ~9 us per launch (2.8 ms per step, 88 % of the GPU time
+    // of a static step) and falls behind the GPU in the run of short kernels.  The per-step stream state lives in the device
+    // descriptor, so the recorded launches depend only on the launch geometry: batch, tokens, key-split shape, the
+    // frozen-static flags and the tuning epoch.  One captured graph therefore serves every step of that shape - any cache
+    // policy, any stream - and is replayed; it is captured on a private stream the second time a shape is seen (every lazily
+    // set kernel attribute has been set by then); any failure falls back to direct launches for that shape.  The descriptor
+    // upload, the sink re-rotation and the input / score copies stay outside the graph.
+    const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
+    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0);
+    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp) {
         aha_ctx::GraphEntry* ge = nullptr;
         for (auto& g : c->graphs)
-            if (g.B == B && g.T == T && g.epoch == c->tune_epoch && memcmp(&g.sd, &sd, sizeof(sd)) == 0) { ge = &g; break; }
+            if (g.B == B && g.T == T && g.epoch == c->tune_epoch && g.n_splits == n_splits && g.split_len == split_len && g.flags == gflags) {
+                ge = &g;
+                break;
+            }
         if (!ge) {
-            if (c->graphs.size() >= 8) {                     // small cache: drop the oldest entry
+            if (c->graphs.size() >= 16) {                    // small cache: drop the oldest entry
                 if (c->graphs.front().exec) hipGraphExecDestroy(c->graphs.front().exec);
                 c->graphs.erase(c->graphs.begin());
             }
             c->graphs.emplace_back();
             ge = &c->graphs.back();
-            ge->sd = sd; ge->B = B; ge->T = T; ge->epoch = c->tune_epoch;
+            ge->B = B; ge->T = T; ge->epoch = c->tune_epoch; ge->n_splits = n_splits; ge->split_len = split_len; ge->flags = gflags;
         }
         if (!ge->exec && !ge->failed && ge->seen >= 1) {
             hipGraph_t graph = nullptr;
@@ -1047,7 +1071,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         if (ge->exec) {
             HIPCHK(c, hipGraphLaunch(ge->exec, st));
             HIPCHK(c, hipMemcpyAsync(out_scores, c->graph_scores, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
-            c->last_weight_bytes = ge->wb; c->last_flops = ge->fl;
+            c->last_weight_bytes = ge->wb; c->last_flops = ge->fl + attn_flops;
             for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = ge->ev_used[k]; c->gk_bytes[k] = ge->gk_bytes[k]; }   // captured event pairs re-record on replay
             c->last_B = B;
             c->last_T = T;
@@ -1055,6 +1079,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         }
     }
     if (const int brc = layers_and_heads(st, out_scores)) return brc;
+    c->last_flops += attn_flops;
     c->last_B = B;
     c->last_T = T;
     return 0;

@@ -28,7 +28,7 @@ template <int D> struct AttnCfg {
 };
 
 template <int D, bool LM>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
     using C = AttnCfg<D>;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, StepDesc sd) 
     int ldk;
     StreamStep ss;
     if constexpr (LM) {
-        ss = sd.s[b];
+        ss = sdp->s[b];                                     // device-resident step descriptor (uploaded once per step)
         Lk = ss.len_after;
         off = ss.causal_off;
         const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * a.hd;
@@ -470,10 +470,10 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
 
 // Merge key splits: one block of D threads per (b, kv head, row).
 template <int D>
-__global__ void attn_combine_kernel(AttnArgs a, StepDesc sd) {
+__global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), Rpad = RT * 16;
     const int r = blockIdx.x, hk = blockIdx.y, b = blockIdx.z, d = threadIdx.x;
-    const int Lk = sd.s[b].len_after;
+    const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
     float M = -INFINITY;
@@ -493,13 +493,13 @@ static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of t
 extern "C" void aha_attention_set_dense_tpw(int v) { g_dense_tpw = v; }
 
 template <int D>
-static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipStream_t st) {
+static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, hipStream_t st) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
     dim3 grid(a.n_splits, a.Hkv * RG, B);
-    if (sd) {
-        hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, st, a, *sd);
+    if (sd_dev) {
+        hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, st, a, sd_dev);
         if (a.n_splits > 1)
-            hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, *sd);
+            hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, sd_dev);
     } else {
         // dense (vision tower): one query tile per wave while the grid is small (single-frame latency), more tiles per
         // wave (less K/V staging per flop) once it fills the chip several times over
@@ -522,7 +522,7 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd, int B, hipS
     return hipGetLastError();
 }
 
-// sd == nullptr: dense (ViT) mode, requires n_splits == 1.
+// sd_dev: DEVICE pointer to the step descriptor (LM mode), or nullptr: dense (ViT) mode, requires n_splits == 1.
 // head_dim: any multiple of 8 up to 128; it runs the 64- or 128-wide template with the surplus
 // channels zero-padded on chip (so400m: 72 -> 128).
 extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int B, int head_dim, hipStream_t st) {

@@ -68,11 +68,11 @@ __global__ __launch_bounds__(512) void resid_norm_kernel(ResidNormArgs a) {
 // ---------------------------------------------------------------------------------------------
 
 template <int D>
-__global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, StepDesc sd) {
+__global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, const StepDesc* __restrict__ sdp) {
     constexpr int HALF = D / 2, IPH = HALF / 4;           // items (4 rotation pairs) per head
     const int row = blockIdx.x, tid = threadIdx.x;
-    const int b = row / sd.T, t = row % sd.T;
-    const StreamStep ss = sd.s[b];
+    const int T = sdp->T, b = row / T, t = row % T;
+    const StreamStep ss = sdp->s[b];
     int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
     const bool store_kv = ss.write_base >= 0 && t < ss.write_count;
     int slot = 0;
@@ -152,11 +152,13 @@ __global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, StepD
 // grid: (key blocks, layers*Hkv, B); block 256 threads = (256 / (D/8)) keys x D/8 items.
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void sink_rerotate_kernel(StepDesc sd, const bf16* __restrict__ rcos,
-                                                            const bf16* __restrict__ rsin, int layers, int Hkv) {
+__global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __restrict__ sdp, unsigned stream_mask,
+                                                            const bf16* __restrict__ rcos, const bf16* __restrict__ rsin,
+                                                            int layers, int Hkv) {
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
     const int b = blockIdx.z;
-    const StreamStep ss = sd.s[b];
+    if (!((stream_mask >> b) & 1u)) return;                 // streams that share this launch's (W, sink, T) table
+    const StreamStep ss = sdp->s[b];
     const int key = blockIdx.x * KPB + threadIdx.x / IPK;
     if (key >= ss.n_rerot) return;
     const int d = (threadIdx.x % IPK) * 4;
@@ -410,28 +412,25 @@ hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st) {
     hipLaunchKernelGGL(resid_norm_kernel, dim3(M), dim3(threads), 0, st, *a);
     return hipGetLastError();
 }
-hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd, hipStream_t st) {
-    const int M = sd->B * sd->T;
+hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, hipStream_t st) {
     const int items = (a->Hq + a->Hkv) * (a->D / 8) + a->Hkv * (a->D / 4);              // one item per thread
     const int threads = 128;
     int groups = ceil_div(items, threads);
     if (groups > 16) groups = 16;
-    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M, groups), dim3(threads), 0, st, *a, *sd);
-    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M, groups), dim3(threads), 0, st, *a, *sd);
+    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M, groups), dim3(threads), 0, st, *a, sd_dev);
+    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M, groups), dim3(threads), 0, st, *a, sd_dev);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t aha_sink_rerotate(const StepDesc* sd, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D,
-                             hipStream_t st) {
-    int nmax = 0;
-    for (int b = 0; b < sd->B; ++b) nmax = sd->s[b].n_rerot > nmax ? sd->s[b].n_rerot : nmax;
-    if (nmax == 0) return hipSuccess;
+hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin,
+                             int layers, int Hkv, int D, hipStream_t st) {
+    if (nmax == 0 || stream_mask == 0) return hipSuccess;
     if (D == 64) {
         const int kpb = 256 / (64 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, sd->B), dim3(256), 0, st, *sd, rcos, rsin, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, layers, Hkv);
     } else if (D == 128) {
         const int kpb = 256 / (128 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, sd->B), dim3(256), 0, st, *sd, rcos, rsin, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, layers, Hkv);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }

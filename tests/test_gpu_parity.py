@@ -783,3 +783,45 @@ def test_clip_vision_encode_contract():
     assert gb.shape == (2 * 49, 256) and torch.isfinite(gb).all()
     assert (gb - wantb).abs().max().item() <= 0.03 * max(1.0, wantb.abs().max().item())
     rtb.close()
+
+
+@pytest.mark.parametrize("policy", ["default_sink", "sliding_window", "none"])
+def test_graph_replay_serves_every_cache_policy_bit_identically(tiny128, bench_rt, policy):
+    """The step descriptor is device-resident, so a captured graph depends only on the launch geometry and is replayed
+    for evicting / growing caches too.  Direct launches and replay must agree bit for bit while the key-split shape
+    changes as the cache grows, across the first evictions + re-rotations, and for a two-stream step whose streams
+    have different lengths."""
+    cfg, _, rt = tiny128
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    g = torch.Generator().manual_seed(21)
+    pre = (torch.randn(2, 17, H, generator=g) * 0.3).bfloat16().cuda()
+    xs = (torch.randn(40, 2, tf, H, generator=g) * 0.3).bfloat16().cuda()
+    outs = []
+    rt.set_tuning("attn_split_len", 64)               # several key splits at this small size
+    for mode in (0, 1):
+        rt.set_tuning("use_graph", mode)
+        a, b = rt.open_stream(policy, 200, 8), rt.open_stream(policy, 200, 8)
+        rt.lm_step([a], pre[0:1])
+        rt.lm_step([b], pre[1:2, :11].contiguous())   # stream b is 6 tokens shorter
+        got = [rt.lm_step([a, b], xs[i].contiguous()).clone() for i in range(40)]   # 17 + 40*9 tokens > window 200: evicts
+        got += [rt.lm_step([a], xs[i, 0:1].contiguous()).clone() for i in range(5)]
+        outs.append(torch.cat([o.view(-1) for o in got]).cpu())
+        assert a.get_seq_length() == (200 if policy != "none" else 17 + 45 * tf)
+        a.close(); b.close()
+    rt.set_tuning("use_graph", 1)
+    rt.set_tuning("attn_split_len", 0)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+    if policy == "default_sink":                      # full size, through the first evictions at W = 2048
+        cfgb, rtb = bench_rt
+        Hb, tfb = cfgb.lm.hidden_size, cfgb.frame_num_tokens
+        xb = (torch.randn(70, tfb, Hb, generator=g) * 0.05).bfloat16().cuda()
+        res = []
+        for mode in (0, 1):
+            rtb.set_tuning("use_graph", mode)
+            st = rtb.open_stream("default_sink", 2048, 32)
+            rtb.lm_step([st], xb[0:1, :20].contiguous())
+            res.append(torch.cat([rtb.lm_step([st], xb[i:i + 1]).clone() for i in range(70)]).cpu())
+            assert st.get_seq_length() == 2048
+            st.close()
+        rtb.set_tuning("use_graph", 1)
+        assert torch.equal(res[0], res[1])

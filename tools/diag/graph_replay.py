@@ -6,6 +6,7 @@ from aha_amd.config import preset
 from aha_amd.synth import make_weights
 from aha_amd.runtime import Runtime
 cfg = preset(sys.argv[1] if len(sys.argv) > 1 else "bench")
+policy = sys.argv[2] if len(sys.argv) > 2 else "static"
 rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True), max_step_tokens=128, max_vit_frames=1)
 torch.cuda.empty_cache()
 H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
@@ -15,7 +16,9 @@ X = (torch.randn(12, tf, H, generator=g) * 0.05).bfloat16().cuda()
 outs = {}
 for mode in (0, 1, 0, 1):
     rt.set_tuning("use_graph", mode)
-    st = rt.open_stream("static", 2048, 0)
+    st = rt.open_stream(policy, 2048, 32 if policy == "default_sink" else 0)
+    if policy != "static":
+        for _ in range(60): rt.lm_step([st], X[0:1])          # fill the window (evicting steady state)
     rt.lm_step([st], prefix)
     sc = torch.cat([rt.lm_step([st], X[i:i + 1]).clone() for i in range(12)]).cpu()
     torch.cuda.synchronize(); t = time.perf_counter()
