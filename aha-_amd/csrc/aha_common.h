@@ -58,8 +58,9 @@ static __host__ __device__ __forceinline__ int ceil_div(int a, int b) { return (
 static __host__ __device__ __forceinline__ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // ---------------------------------------------------------------------------------------------
-// Per-step description of the streams an lm_step works on.  Passed to kernels BY VALUE (kernarg),
-// so a step needs no host->device copy and no sync.  Logical key index j of a stream maps to a
+// Per-step description of the streams an lm_step works on.  It is DEVICE-RESIDENT: the host fills one (plan_stream),
+// uploads it from a pinned ring slot once per step (1 KB, asynchronous) and every kernel reads it through the same constant
+// pointer - so the launches of a step do not bake the stream state in and a captured HIP graph can be replayed.  Logical key index j of a stream maps to a
 // physical cache slot through (n_fixed, ring_head, ring_cap):
 //     j <  n_fixed : slot j                      (NONE/STATIC: everything; SINK: the sink tokens)
 //     j >= n_fixed : slot n_fixed + (ring_head + (j - n_fixed)) % ring_cap
