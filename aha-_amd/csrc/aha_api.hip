@@ -64,6 +64,7 @@ struct aha_ctx {
         double wb = 0, fl = 0; int ev_used[8] = {0}; double gk_bytes[8] = {0};      // bookkeeping of the captured step
     };
     std::vector<GraphEntry> graphs;
+    std::vector<hipGraphExec_t> retired_graphs;
     hipStream_t cap_stream = nullptr;
     float* graph_scores = nullptr;
     int use_graph = 1, tune_epoch = 0;
@@ -222,6 +223,7 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     hipDeviceSynchronize();
     for (auto& g : c->graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
+    for (auto e : c->retired_graphs) hipGraphExecDestroy(e);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->sd_pin) hipHostFree(c->sd_pin);
     for (void* p : c->allocs) hipFree(p);
@@ -1043,8 +1045,8 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 break;
             }
         if (!ge) {
-            if (c->graphs.size() >= 16) {                    // small cache: drop the oldest entry
-                if (c->graphs.front().exec) hipGraphExecDestroy(c->graphs.front().exec);
+            if (c->graphs.size() >= 32) {                    // small cache: drop the oldest shape; its executable may in principle
+                if (c->graphs.front().exec) c->retired_graphs.push_back(c->graphs.front().exec);   // still be queued: destroyed with the ctx
                 c->graphs.erase(c->graphs.begin());
             }
             c->graphs.emplace_back();
