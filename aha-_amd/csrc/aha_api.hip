@@ -1045,9 +1045,16 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 break;
             }
         if (!ge) {
-            if (c->graphs.size() >= 32) {                    // small cache: drop the oldest shape; its executable may in principle
-                if (c->graphs.front().exec) c->retired_graphs.push_back(c->graphs.front().exec);   // still be queued: destroyed with the ctx
+            if (c->graphs.size() >= 64) {                    // more shapes than a 32k-token growing cache sweeps through (~44)
+                // drop the oldest shape; its executable may in principle still be queued, so it is only retired here and
+                // destroyed behind a device synchronisation once a few have piled up (rare), or with the context
+                if (c->graphs.front().exec) c->retired_graphs.push_back(c->graphs.front().exec);
                 c->graphs.erase(c->graphs.begin());
+                if (c->retired_graphs.size() >= 16) {
+                    HIPCHK(c, hipDeviceSynchronize());
+                    for (auto e : c->retired_graphs) hipGraphExecDestroy(e);
+                    c->retired_graphs.clear();
+                }
             }
             c->graphs.emplace_back();
             ge = &c->graphs.back();
