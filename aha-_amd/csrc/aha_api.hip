@@ -54,11 +54,17 @@ struct aha_ctx {
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
+    std::map<std::tuple<int, int, int>, hipStream_t> rerot_stream;   // stream a device-built table was enqueued on (later LM work is ordered behind it by ORDER_LM)
     // HIP-graph replay of frozen TrulyStaticCache steps (tuning "use_graph"): cached executables keyed by the exact step
     // device-resident step descriptor: written to a pinned ring slot and uploaded once per step (1 KB), so kernels take a
     // constant pointer and a captured graph does not bake the per-step stream state in
     StepDesc* sd_pin = nullptr; StepDesc* sd_dev = nullptr; int sd_slot = 0;
     static constexpr int SD_SLOTS = 256;
+    hipEvent_t sd_ev[SD_SLOTS] = {nullptr};                 // recorded behind each slot's upload; waited on before the slot is reused
+    // the LM / vision workspaces belong to the context: work submitted on a different HIP stream than the previous call's is
+    // ordered behind it with an event (correct, merely serialised) instead of racing on them
+    hipStream_t last_lm_stream = nullptr, last_vit_stream = nullptr; bool lm_stream_set = false, vit_stream_set = false;
+    hipEvent_t lm_done = nullptr, vit_done = nullptr;
     struct GraphEntry {
         int B = 0, T = 0, epoch = 0, n_splits = 0, split_len = 0, flags = 0, seen = 0; hipGraphExec_t exec = nullptr; bool failed = false;
         double wb = 0, fl = 0; int ev_used[8] = {0}; double gk_bytes[8] = {0};      // bookkeeping of the captured step
@@ -70,7 +76,9 @@ struct aha_ctx {
     int use_graph = 1, tune_epoch = 0;
     // fused MLP block (lm_fused.hip): device arrival counter + its host-side base, error flag, switch
     unsigned long long* bar_ctr = nullptr; unsigned long long bar_base = 0; int* bar_err = nullptr; int fuse_mlp = 0, n_cus = 0;
-    struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0; };
+    struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0;
+                       hipStream_t up_stream = nullptr; hipEvent_t ready = nullptr; };   // tables are uploaded on up_stream; other streams wait on `ready`
+    std::vector<void*> pinned;                               // host staging of coefficient tables (kept: async uploads read them)
     std::map<std::tuple<int, int, int>, IngestTab> ingest_tabs;      // (method, h, w) -> device coefficient tables
     // LM workspaces
     bf16 *h = nullptr, *xn = nullptr, *q_rot = nullptr, *attn_out = nullptr, *act = nullptr;
@@ -99,6 +107,7 @@ struct aha_ctx {
 
 struct aha_stream {
     aha_ctx* ctx;
+    int device = 0;                      // aha_stream_destroy must not dereference ctx (it may already be gone)
     int policy, W, sink, cap;
     bf16 *k = nullptr, *v = nullptr;
     int len = 0, head = 0, seen = 0;
@@ -127,6 +136,23 @@ static int dalloc(aha_ctx* c, T** out, size_t count) {
     *out = reinterpret_cast<T*>(p);
     return 0;
 }
+
+// Order work submitted on `st` behind everything the previous call of the same family (LM / vision) submitted on another
+// stream: the workspaces belong to the context, so two streams must not run on them concurrently.
+static int order_behind(aha_ctx* c, hipStream_t st, hipStream_t* last, bool* set, hipEvent_t* ev) {
+    if (*set && *last != st) {
+        if (!*ev) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        if (hipEventRecord(*ev, *last) != hipSuccess || hipStreamWaitEvent(st, *ev, 0) != hipSuccess) {
+            (void)hipGetLastError();                     // the previous stream is gone: its work is ordered by a full sync
+            HIPCHK(c, hipDeviceSynchronize());
+        }
+    }
+    *last = st;
+    *set = true;
+    return 0;
+}
+#define ORDER_LM(c, st) do { if (int rc_ = order_behind((c), (st), &(c)->last_lm_stream, &(c)->lm_stream_set, &(c)->lm_done)) return rc_; } while (0)
+#define ORDER_VIT(c, st) do { if (int rc_ = order_behind((c), (st), &(c)->last_vit_stream, &(c)->vit_stream_set, &(c)->vit_done)) return rc_; } while (0)
 
 // --------------------------------------------------------------------------------------------
 extern "C" const char* aha_version(void) { return "aha_amd 0.1 (gfx950)"; }
@@ -226,6 +252,11 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     for (auto e : c->retired_graphs) hipGraphExecDestroy(e);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
     if (c->sd_pin) hipHostFree(c->sd_pin);
+    for (auto e : c->sd_ev) if (e) hipEventDestroy(e);
+    if (c->lm_done) hipEventDestroy(c->lm_done);
+    if (c->vit_done) hipEventDestroy(c->vit_done);
+    for (void* p : c->pinned) hipHostFree(p);
+    for (auto& kv : c->ingest_tabs) if (kv.second.ready) hipEventDestroy(kv.second.ready);
     for (void* p : c->allocs) hipFree(p);
     for (int k = 0; k < GK_COUNT; ++k)
         for (auto& pr : c->ev[k]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -300,6 +331,8 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
     if (c) c->tune_epoch++;                                  // captured graphs hold pointers into the old tables
 
     if (!c || !tensors) return AHA_E_INVAL;
+    if (c->weights_loaded || !c->L.empty())
+        return fail(c, AHA_E_INVAL, "weights were already loaded into this context (create a new context to load another checkpoint)");
     hipStream_t st = (hipStream_t)st_;
     HIPCHK(c, hipSetDevice(c->device));
     TMap m;
@@ -479,6 +512,7 @@ extern "C" int aha_stream_open(aha_ctx* c, int policy, int window, int n_sink, i
     if (policy == AHA_CACHE_NONE && capacity <= 0) return fail(c, AHA_E_INVAL, "capacity must be > 0");
     aha_stream* s = new aha_stream();
     s->ctx = c;
+    s->device = c->device;
     s->policy = policy;
     s->W = window;
     s->sink = policy == AHA_CACHE_SINK ? n_sink : 0;
@@ -514,7 +548,7 @@ extern "C" int aha_stream_set_position_offset(aha_stream* s, int offset) {
 }
 extern "C" void aha_stream_destroy(aha_stream* s) {
     if (!s) return;
-    hipSetDevice(s->ctx->device);
+    hipSetDevice(s->device);
     hipDeviceSynchronize();
     hipFree(s->k);
     hipFree(s->v);
@@ -684,10 +718,17 @@ static int vit_check(aha_ctx* c, const void* frames, const void* out, int n) {
 void aha_ingest_pil_tables(int in_size, int out_size, int* ksize_out, std::vector<int>* bounds, std::vector<int>* kk);
 void aha_ingest_cv_tables(int src_size, int dst_size, bool horizontal, std::vector<int>* tab);
 
-static int upload_ints(aha_ctx* c, const std::vector<int>& v, int** dst) {
+// once per geometry: staged in pinned host memory that lives as long as the context, copied asynchronously on the caller's
+// stream (the ingest kernel that reads the table is enqueued behind it) - no host synchronisation on the frame path
+static int upload_ints(aha_ctx* c, const std::vector<int>& v, int** dst, hipStream_t st) {
     int rc = dalloc(c, dst, v.size());
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));   // once per geometry
+    void* pin = nullptr;
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(int);
+    if (hipHostMalloc(&pin, bytes, hipHostMallocDefault) != hipSuccess) return fail(c, AHA_E_NOMEM, "hipHostMalloc failed");
+    c->pinned.push_back(pin);
+    memcpy(pin, v.data(), v.size() * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(*dst, pin, v.size() * sizeof(int), hipMemcpyHostToDevice, st));
     return 0;
 }
 
@@ -712,22 +753,26 @@ extern "C" int aha_frame_ingest(aha_ctx* c, const uint8_t* src, int height, int 
             std::vector<int> b, k;
             if (new_w != width) {
                 aha_ingest_pil_tables(width, new_w, &t.xks, &b, &k);
-                if ((rc = upload_ints(c, b, &t.xb)) || (rc = upload_ints(c, k, &t.xk))) return rc;
+                if ((rc = upload_ints(c, b, &t.xb, (hipStream_t)st_)) || (rc = upload_ints(c, k, &t.xk, (hipStream_t)st_))) return rc;
             }
             if (new_h != height) {
                 aha_ingest_pil_tables(height, new_h, &t.yks, &b, &k);
-                if ((rc = upload_ints(c, b, &t.yb)) || (rc = upload_ints(c, k, &t.yk))) return rc;
+                if ((rc = upload_ints(c, b, &t.yb, (hipStream_t)st_)) || (rc = upload_ints(c, k, &t.yk, (hipStream_t)st_))) return rc;
             }
         } else if (new_w != width || new_h != height) {
             std::vector<int> tab;
             aha_ingest_cv_tables(width, new_w, true, &tab);
-            if ((rc = upload_ints(c, tab, &t.xb))) return rc;
+            if ((rc = upload_ints(c, tab, &t.xb, (hipStream_t)st_))) return rc;
             aha_ingest_cv_tables(height, new_h, false, &tab);
-            if ((rc = upload_ints(c, tab, &t.yb))) return rc;
+            if ((rc = upload_ints(c, tab, &t.yb, (hipStream_t)st_))) return rc;
         }
+        t.up_stream = (hipStream_t)st_;
+        HIPCHK(c, hipEventCreateWithFlags(&t.ready, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(t.ready, t.up_stream));
         it = c->ingest_tabs.emplace(key, t).first;
     }
     const aha_ctx::IngestTab& t = it->second;
+    if (t.up_stream != (hipStream_t)st_) HIPCHK(c, hipStreamWaitEvent((hipStream_t)st_, t.ready, 0));
     IngestArgs a{};
     a.src = src; a.h = height; a.w = width; a.src_bgr = src_is_bgr ? 1 : 0;
     a.out = out; a.S = S;
@@ -742,6 +787,7 @@ extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* ou
     int rc = vit_check(c, frames, out_embeds, n);
     if (rc || n <= 0) return rc;
     hipStream_t st = (hipStream_t)st_;
+    ORDER_VIT(c, st);
     const aha_model_desc& d = c->d;
     // With a CLIP tower (LLaVA's select_feature = 'patch') the projector also runs over the class-token rows (1 in Np + 1,
     // cheaper than compacting) and the pooling reads the Np patch rows of each frame's Tt.
@@ -764,6 +810,7 @@ extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, in
     if (!clip && !c->post_ln_w) return fail(c, AHA_E_NOENT, "vision.post_layernorm.{weight,bias} were not loaded");
     if (pooled <= 0 || pooled > c->grid) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid");
     hipStream_t st = (hipStream_t)st_;
+    ORDER_VIT(c, st);
     const aha_model_desc& d = c->d;
     const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden, prow = n * pooled * pooled;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
@@ -784,6 +831,7 @@ extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, in
 extern "C" int aha_vit_last_tower_output(aha_ctx* c, int n_frames, void* out, aha_hip_stream st) {
     if (!c || !out || n_frames <= 0 || n_frames > c->d.max_vit_frames) return AHA_E_INVAL;
     // rows per frame: Np (SigLIP) or Np + 1 with the class token as the LAST row (CLIP)
+    ORDER_VIT(c, (hipStream_t)st);
     HIPCHK(c, hipMemcpyAsync(out, c->v_x, (size_t)n_frames * c->Tt * c->d.v_hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
     return 0;
 }
@@ -880,18 +928,40 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     memset(&sd, 0, sizeof(sd));
     sd.B = B;
     sd.T = T;
-    int saved[AHA_MAX_B][3];
+    // Host bookkeeping is advanced by plan_stream BEFORE any device work is enqueued; this guard puts every stream back
+    // if anything after it fails (planning, table build, descriptor upload, a launch, graph capture / replay), so a
+    // caller that retries or continues never attends over slots that were never written.
+    struct Rollback {
+        aha_stream* const* streams; int n = 0; int saved[AHA_MAX_B][3]; bool armed = true;
+        ~Rollback() {
+            if (!armed) return;
+            for (int b = n - 1; b >= 0; --b) { streams[b]->len = saved[b][0]; streams[b]->head = saved[b][1]; streams[b]->seen = saved[b][2]; }
+        }
+    } guard{streams};
     for (int b = 0; b < B; ++b) {
         aha_stream* s = streams[b];
-        saved[b][0] = s->len; saved[b][1] = s->head; saved[b][2] = s->seen;
+        guard.saved[b][0] = s->len; guard.saved[b][1] = s->head; guard.saved[b][2] = s->seen;
+        guard.n = b + 1;
         int rc = plan_stream(c, s, T, &sd.s[b]);
         if (!rc && sd.s[b].pos_base + T > c->n_pos) rc = fail(c, AHA_E_RANGE, "position exceeds the RoPE table");
-        if (!rc && sd.s[b].n_rerot > 0 && !c->rerot.count(std::make_tuple(s->W, s->sink, T)))
-            rc = fail(c, AHA_E_NOENT, "re-rotation table for (window, n_sink, T) not set");
-        if (rc) {                                       // roll back every stream touched so far
-            for (int b2 = 0; b2 <= b; ++b2) { streams[b2]->len = saved[b2][0]; streams[b2]->head = saved[b2][1]; streams[b2]->seen = saved[b2][2]; }
-            return rc;
-        }
+        if (rc) return rc;
+    }
+    ORDER_LM(c, st);
+    // SinkCache re-rotation tables this step needs, built on the device from the RoPE table the first time a
+    // (window, n_sink, T) combination evicts: asynchronous on `st`, no host round trip (test/sink_cache.py:35-55)
+    for (int b = 0; b < B; ++b) {
+        if (sd.s[b].n_rerot == 0) continue;
+        const aha_stream* s = streams[b];
+        const auto key = std::make_tuple(s->W, s->sink, T);
+        if (c->rerot.count(key)) continue;
+        if (s->W > c->n_pos) return fail(c, AHA_E_RANGE, "SinkCache window exceeds the RoPE table");
+        const int rows = s->W - s->sink - T;
+        bf16 *pc, *ps;
+        int rc;
+        if ((rc = dalloc(c, &pc, (size_t)rows * Dh)) || (rc = dalloc(c, &ps, (size_t)rows * Dh))) return rc;
+        HIPCHK(c, aha_rerot_table(c->rope_cos, c->rope_sin, Dh, s->sink, T, rows, pc, ps, st));
+        c->rerot[key] = {pc, ps};
+        c->rerot_stream[key] = st;
     }
     c->last_weight_bytes = c->last_kv_bytes = c->last_flops = 0;
     for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
@@ -904,11 +974,17 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     }
     {
         // Upload this step's descriptor (pinned ring slot -> the one device copy; stream order keeps the previous step's
-        // kernels ahead of the overwrite; the ring is far deeper than the launches a HIP queue can hold).
-        StepDesc* slot = c->sd_pin + c->sd_slot;
-        c->sd_slot = (c->sd_slot + 1) % aha_ctx::SD_SLOTS;
+        // kernels ahead of the overwrite).  A slot is rewritten only after the upload that last read it has completed:
+        // an event recorded behind each upload is waited on before reuse - free when the caller synchronises every step,
+        // and a real wait only for a caller that runs more than SD_SLOTS steps ahead of the GPU.
+        const int si = c->sd_slot;
+        StepDesc* slot = c->sd_pin + si;
+        c->sd_slot = (si + 1) % aha_ctx::SD_SLOTS;
+        if (c->sd_ev[si]) HIPCHK(c, hipEventSynchronize(c->sd_ev[si]));
+        else HIPCHK(c, hipEventCreateWithFlags(&c->sd_ev[si], hipEventDisableTiming));
         *slot = sd;
         HIPCHK(c, hipMemcpyAsync(c->sd_dev, slot, sizeof(StepDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->sd_ev[si], st));
         // streams sharing (W, sink) share the table; one launch per group, selected by a stream mask
         bool done[AHA_MAX_B] = {false};
         for (int b = 0; b < B; ++b) {
@@ -1037,7 +1113,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     // upload, the sink re-rotation and the input / score copies stay outside the graph.
     const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
     const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0);
-    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp) {
+    // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
+    // does not become a graph node, so a replay would leave the events holding stale timestamps.)
+    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp && !c->time_gemm) {
         aha_ctx::GraphEntry* ge = nullptr;
         for (auto& g : c->graphs)
             if (g.B == B && g.T == T && g.epoch == c->tune_epoch && g.n_splits == n_splits && g.split_len == split_len && g.flags == gflags) {
@@ -1081,9 +1159,10 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             HIPCHK(c, hipGraphLaunch(ge->exec, st));
             HIPCHK(c, hipMemcpyAsync(out_scores, c->graph_scores, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
             c->last_weight_bytes = ge->wb; c->last_flops = ge->fl + attn_flops;
-            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = ge->ev_used[k]; c->gk_bytes[k] = ge->gk_bytes[k]; }   // captured event pairs re-record on replay
+            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }   // a replay records no GEMM events (time_gemm steps are launched directly)
             c->last_B = B;
             c->last_T = T;
+            guard.armed = false;
             return 0;
         }
     }
@@ -1091,17 +1170,20 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     c->last_flops += attn_flops;
     c->last_B = B;
     c->last_T = T;
+    guard.armed = false;
     return 0;
 }
 
 extern "C" int aha_lm_heads_all(aha_ctx* c, float* out_raw, aha_hip_stream st) {
     if (!c || !out_raw || c->last_B == 0) return AHA_E_INVAL;
+    ORDER_LM(c, (hipStream_t)st);
     HIPCHK(c, aha_heads(c->xn, c->d.hidden, 0, 1, c->last_B * c->last_T, c->heads_w, c->d.hidden, nullptr, out_raw, c->bar_err, (hipStream_t)st));
     return 0;
 }
 
 extern "C" int aha_lm_last_hidden_all(aha_ctx* c, void* out, aha_hip_stream st) {
     if (!c || !out || c->last_B == 0) return AHA_E_INVAL;
+    ORDER_LM(c, (hipStream_t)st);
     HIPCHK(c, hipMemcpyAsync(out, c->xn, (size_t)c->last_B * c->last_T * c->d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
     return 0;
 }
@@ -1110,6 +1192,7 @@ extern "C" int aha_lm_logits_last(aha_ctx* c, float* logits, int64_t* argmax, ah
     if (!c || c->last_B == 0) return AHA_E_INVAL;
     if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
     hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
     const int B = c->last_B, T = c->last_T, H = c->d.hidden, V = c->d.vocab;
     float* lg = logits ? logits : c->logits;
     // last-token rows are strided by T*H in xn: ldx = T*H makes them the M = B rows of the GEMM

@@ -180,6 +180,28 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// SinkCache._get_rerotation_cos_sin (test/sink_cache.py:35-55) for T new tokens, built ON THE DEVICE from the bf16 RoPE
+// table so that no host table, upload or synchronisation sits in the first evicting step of a stream:
+//   original = table[sink+T + i], shifted = table[sink + i]   (i < W - sink - T), both widened to fp32
+//   cos_r = oc*sc + os*ss ;  sin_r = -os*sc + oc*ss   -> bf16
+// torch evaluates each product and each sum as its own fp32 op, so contraction into FMAs is switched off here
+// (checked in the ISA: v_mul_f32 / v_add_f32 only).
+// ---------------------------------------------------------------------------------------------
+__global__ void rerot_table_kernel(const bf16* __restrict__ cosb, const bf16* __restrict__ sinb, int D, int sink, int T, int rows,
+                                   bf16* __restrict__ rc, bf16* __restrict__ rs) {
+#pragma clang fp contract(off)
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)rows * D) return;
+    const int i = (int)(gid / D), d = (int)(gid % D);
+    const float oc = bf2f(cosb[(long)(sink + T + i) * D + d]), os = bf2f(sinb[(long)(sink + T + i) * D + d]);
+    const float sc = bf2f(cosb[(long)(sink + i) * D + d]), ss = bf2f(sinb[(long)(sink + i) * D + d]);
+    const float p0 = oc * sc, p1 = os * ss, p2 = (-os) * sc, p3 = oc * ss;
+    const float c = p0 + p1, s = p2 + p3;
+    rc[gid] = f2bf(rbf(c));
+    rs[gid] = f2bf(rbf(s));
+}
+
+// ---------------------------------------------------------------------------------------------
 // The three scoring heads on final-normed hidden rows (video_head_live_llava_qwen.py:185-188) and
 // the score post-ops of _encode_frame (test/inference.py:222-227).  heads_w = [info0; info1; rel; unc]
 // rows of H.  Row i of the launch reads hidden row (row_first + i*row_step).
@@ -432,6 +454,12 @@ hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n
         const int kpb = 256 / (128 / 8);
         hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, layers, Hkv);
     } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t aha_rerot_table(const bf16* cosb, const bf16* sinb, int D, int sink, int T, int rows, bf16* rc, bf16* rs, hipStream_t st) {
+    const long total = (long)rows * D;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rerot_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cosb, sinb, D, sink, T, rows, rc, rs);
     return hipGetLastError();
 }
 hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H,

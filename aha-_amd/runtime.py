@@ -3,6 +3,7 @@ FLOP of the hot path runs in libaha_amd.so.  Nothing here imports ``oracle``."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -55,6 +56,7 @@ class Stream:
         h = C.c_void_p()
         rt._chk(rt.lib.aha_stream_open(rt.ctx, self.policy, window_length, num_sink_tokens, capacity, C.byref(h)))
         self.handle = h
+        rt._streams.add(self)
         if attn_semantics != "trailing":
             rt._chk(rt.lib.aha_stream_set_attn_semantics(h, _l.ATTN_HF449_SDPA))
 
@@ -81,9 +83,11 @@ class Stream:
         return out
 
     def close(self):
-        if self.handle is not None and self.rt.ctx is not None:
+        # aha_stream_destroy does not touch the context, so a stream may outlive its Runtime without leaking its K/V buffers
+        if self.handle is not None:
             self.rt.lib.aha_stream_destroy(self.handle)
         self.handle = None
+        self.rt._streams.discard(self)
 
     def __del__(self):
         try:
@@ -100,6 +104,7 @@ class Runtime:
         if not torch.cuda.is_available():
             raise AhaError("aha_amd needs a GPU: the product path has no CPU fallback")
         self.lib = _l.get()
+        self._streams = weakref.WeakSet()            # open Streams: closed with the Runtime (their K/V buffers are multi-GB at 7B)
         self.cfg = cfg
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -157,6 +162,8 @@ class Runtime:
         self._chk(self.lib.aha_ctx_set_tuning(self.ctx, key.encode(), int(value)))
 
     def close(self):
+        for s in list(getattr(self, "_streams", ())):
+            s.close()
         if self.ctx is not None:
             self.lib.aha_ctx_destroy(self.ctx)
             self.ctx = None
@@ -172,7 +179,10 @@ class Runtime:
                     capacity: Optional[int] = None, attn_semantics: str = "trailing") -> Stream:
         return Stream(self, alt_cache, window_length, num_sink_tokens, capacity or self.desc.max_positions, attn_semantics)
 
-    def _ensure_rerotation(self, s: Stream, T: int):
+    def set_rerotation_table(self, s: Stream, T: int):
+        """Optional: install a host-computed SinkCache re-rotation table for (window, n_sink, T).  aha_lm_step builds the same
+        table on the device, asynchronously, the first time a combination evicts, so the step path never calls this; it
+        exists for callers that want to supply the table themselves (and for the bit-exactness test of the device build)."""
         if s.policy != _l.CACHE_SINK:
             return
         W, k = s.window_length, s.num_sink_tokens
@@ -255,8 +265,6 @@ class Runtime:
         embeds = embeds.contiguous()
         B, T, _ = embeds.shape
         assert B == len(streams)
-        for s in streams:
-            self._ensure_rerotation(s, T)
         scores = torch.empty((B, 3), dtype=torch.float32, device=self.device)
         raw = torch.empty((B, 4), dtype=torch.float32, device=self.device) if want_raw else None
         hid = torch.empty((B, self.hidden_size), dtype=torch.bfloat16, device=self.device) if want_hidden else None

@@ -8,8 +8,17 @@
  *
  * Conventions: every function returns 0 on success or a negative errno-style code and never
  * throws; aha_last_error() gives the message.  All tensor pointers are DEVICE pointers owned by
- * the caller (bf16 unless stated); KV caches are owned by aha_stream.  Calls enqueue work on
- * the given hipStream_t and do not synchronise.  One aha_ctx per process / GPU; not thread-safe.
+ * the caller (bf16 unless stated); KV caches are owned by aha_stream.  The per-frame calls
+ * (aha_frame_ingest, aha_vit_encode*, aha_embed_tokens, aha_lm_step, aha_lm_heads_all,
+ * aha_lm_last_hidden_all, aha_lm_logits*, aha_generate_greedy, aha_cache_update) enqueue work on the
+ * given hipStream_t and never synchronise with the host, first use included (coefficient and
+ * re-rotation tables are built / uploaded asynchronously on that stream).  Set-up and tear-down calls
+ * (aha_ctx_create / _load_weights / _set_rope_table / _set_rerotation_table / _destroy,
+ * aha_stream_open / _destroy) may block.  One aha_ctx per process / GPU; not thread-safe.  The LM and
+ * vision workspaces belong to the context: a call submitted on a different HIP stream than the
+ * previous call of the same family is ordered behind it with an event (serialised, never racing).
+ * If a per-frame call fails, the streams' bookkeeping (length, ring head, seen tokens) is restored
+ * to what it was before the call.
  */
 #ifndef AHA_AMD_H
 #define AHA_AMD_H
@@ -67,13 +76,16 @@ enum { AHA_ATTN_TRAILING = 0, AHA_ATTN_HF449_SDPA = 1 };
  * (models/__init__.py:8-11, models/modeling_live.py:96-181) for the inference path */
 int aha_ctx_create(const aha_model_desc* desc, int device, aha_ctx** out);
 /* replaces from_pretrained weight materialisation (models/modeling_live.py:137-144).  Tensors are
- * COPIED and repacked into the kernels' private layouts; the caller may free them afterwards. */
+ * COPIED and repacked into the kernels' private layouts; the caller may free them afterwards.
+ * Once per context: a second call is rejected (-22) rather than leaking the first set. */
 int aha_ctx_load_weights(aha_ctx* ctx, const aha_tensor_view* tensors, size_t n, aha_hip_stream st);
 /* RoPE cos/sin table, bf16 [n_pos][head_dim] (Qwen2RotaryEmbedding.forward output cast to bf16,
  * transformers modeling_qwen2.py:87-102); copied. */
 int aha_ctx_set_rope_table(aha_ctx* ctx, const void* cos_bf16, const void* sin_bf16, int n_pos, aha_hip_stream st);
 /* SinkCache._get_rerotation_cos_sin table for new-token count T (test/sink_cache.py:35-55),
- * bf16 [window - n_sink - T][head_dim]; copied, keyed by (window, n_sink, T). */
+ * bf16 [window - n_sink - T][head_dim]; copied, keyed by (window, n_sink, T).  OPTIONAL: aha_lm_step
+ * builds the identical table on the device from the RoPE table (asynchronously, on the step's stream)
+ * the first time a combination evicts; this entry point lets a caller supply its own instead. */
 int aha_ctx_set_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T, const void* cos_bf16,
                                  const void* sin_bf16, aha_hip_stream st);
 int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
