@@ -95,6 +95,11 @@ struct aha_ctx {
     int wpb[GK_COUNT] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
+    int layer_first = 0, layer_count = 0;                   // tuning: run only decoder layers [first, first+count) (0 = all); parity taps
+    // generation scratch (aha_generate_greedy): next-token id, embedding row, penalty temporaries, device history count, host poll slot
+    long* gen_tok = nullptr; bf16* gen_emb = nullptr; float* gen_tmp = nullptr; int* gen_nhist = nullptr; long* gen_out = nullptr;
+    long* gen_pin = nullptr; hipEvent_t gen_ev = nullptr; int gen_cap = 0;
+    // operator-level attention (aha_attention_forward): its own descriptor slot ring is the step's (sd_pin / sd_dev)
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
     // accounting of the last step
@@ -113,6 +118,8 @@ struct aha_stream {
     int len = 0, head = 0, seen = 0;
     int semantics = AHA_ATTN_TRAILING;
     int pos_off = 0;                     // added to the RoPE position of new token 0 (aha_stream_set_position_offset)
+    // operator-level aha_cache_update: the step planned by layer 0's call, followed by the other layers of that step
+    StreamStep op_ss; int op_T = 0, op_next_layer = 0; bool op_valid = false;
 };
 
 static int fail(aha_ctx* c, int code, const std::string& msg) {
@@ -256,6 +263,8 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     if (c->lm_done) hipEventDestroy(c->lm_done);
     if (c->vit_done) hipEventDestroy(c->vit_done);
     for (void* p : c->pinned) hipHostFree(p);
+    if (c->gen_pin) hipHostFree(c->gen_pin);
+    if (c->gen_ev) hipEventDestroy(c->gen_ev);
     for (auto& kv : c->ingest_tabs) if (kv.second.ready) hipEventDestroy(kv.second.ready);
     for (void* p : c->allocs) hipFree(p);
     for (int k = 0; k < GK_COUNT; ++k)
@@ -277,6 +286,8 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "wpb_down") c->wpb[GK_DOWN] = value;
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
+    else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
+    else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
@@ -532,6 +543,7 @@ extern "C" int aha_stream_open(aha_ctx* c, int policy, int window, int n_sink, i
 extern "C" int aha_stream_reset(aha_stream* s) {
     if (!s) return AHA_E_INVAL;
     s->len = s->head = s->seen = 0;
+    s->op_valid = false;
     return 0;
 }
 extern "C" int aha_stream_seq_length(const aha_stream* s) { return s ? s->len : AHA_E_INVAL; }
@@ -1022,12 +1034,17 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
 
     // Everything from the first RMSNorm to the heads, on stream `st`, scores to `scores_out`: run directly, or recorded
     // into a HIP graph (below).
+    int l_first = 0, l_end = d.layers;
+    if (c->layer_count > 0) {
+        l_first = c->layer_first < 0 ? 0 : (c->layer_first >= d.layers ? d.layers - 1 : c->layer_first);
+        l_end = l_first + c->layer_count > d.layers ? d.layers : l_first + c->layer_count;
+    }
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
-        HIPCHK(c, aha_rmsnorm(c->h, H, c->L[0].ln1, c->xn, H, M, H, d.rms_eps, st));
+        HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
 
         int rc;
-        for (int l = 0; l < d.layers; ++l) {
+        for (int l = l_first; l < l_end; ++l) {
             const LayerW& w = c->L[l];
             // QKV projection -> split-K slabs (q tiles only for an all-frozen step, see above)
             PackedW wq = w.qkv;
@@ -1199,6 +1216,282 @@ extern "C" int aha_lm_logits_last(aha_ctx* c, float* logits, int64_t* argmax, ah
     int rc = ws_gemm(c, -1, c->xn + (size_t)(T - 1) * H, T * H, B, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, lg, V, st);
     if (rc) return rc;
     if (argmax) HIPCHK(c, aha_argmax(lg, V, V, B, (long*)argmax, st));
+    return 0;
+}
+
+// all-position lm_head of the last step: outputs.logits [B,T,V] of the reference forward
+// (video_head_live_llava_qwen.py:175), fp32, row-chunked through the weight-streaming GEMM
+extern "C" int aha_lm_logits_all(aha_ctx* c, float* logits, aha_hip_stream st_) {
+    if (!c || !logits || c->last_B == 0) return AHA_E_INVAL;
+    if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    const int M = c->last_B * c->last_T, H = c->d.hidden, V = c->d.vocab;
+    return ws_gemm(c, -1, c->xn, H, M, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, logits, V, st);
+}
+
+// parity tap: copy a workspace of the last aha_lm_step.  which: 0 residual stream h [M][hidden] (= the hidden state after the
+// last executed decoder layer), 1 xn [M][hidden] (h normalised for the next layer / by model.norm), 2 rotated queries
+// [M][heads*head_dim], 3 attention output [M][heads*head_dim], 4 SwiGLU activation [M][inter]; the last three hold the LAST
+// executed layer's values (tuning layer_first / layer_count select it).
+extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream st_) {
+    if (!c || !out || c->last_B == 0) return AHA_E_INVAL;
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    const size_t M = (size_t)c->last_B * c->last_T;
+    const void* src; size_t cols;
+    switch (which) {
+        case 0: src = c->h; cols = c->d.hidden; break;
+        case 1: src = c->xn; cols = c->d.hidden; break;
+        case 2: src = c->q_rot; cols = (size_t)c->d.heads * c->d.head_dim; break;
+        case 3: src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
+        case 4: src = c->act; cols = c->d.inter; break;
+        default: return fail(c, AHA_E_INVAL, "unknown tap");
+    }
+    HIPCHK(c, hipMemcpyAsync(out, src, M * cols * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// operator level
+// --------------------------------------------------------------------------------------------
+struct aha_linear { aha_ctx* ctx; int device; PackedW w; bool pairs; };
+
+extern "C" int aha_linear_create(aha_ctx* c, const void* w, const void* w_up, int N, int K, aha_linear** out, aha_hip_stream st_) {
+    if (!c || !w || !out || N <= 0 || K <= 0) return AHA_E_INVAL;
+    if (K % 8) return fail(c, AHA_E_INVAL, "K must be a multiple of 8");
+    hipStream_t st = (hipStream_t)st_;
+    aha_linear* L = new aha_linear();
+    L->ctx = c; L->device = c->device; L->pairs = w_up != nullptr;
+    const int nt = ceil_div(N, 16);
+    PackedW& pw = L->w;
+    pw.n_tiles = L->pairs ? 2 * nt : nt; pw.K = K; pw.N = N;
+    pw.KS = round_up(ceil_div(K, 32), 8);
+    if (hipMalloc((void**)&pw.p, (size_t)pw.n_tiles * pw.KS * 1024) != hipSuccess) { delete L; return fail(c, AHA_E_NOMEM, "hipMalloc failed"); }
+    hipError_t e = aha_pack_w((const bf16*)w, N, K, K, pw.p, pw.KS, L->pairs ? 2 : 1, 0, st);
+    if (e == hipSuccess && L->pairs) e = aha_pack_w((const bf16*)w_up, N, K, K, pw.p, pw.KS, 2, 1, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);        // set-up call: the sources may be freed on return
+    if (e != hipSuccess) { hipFree(pw.p); delete L; return fail(c, AHA_E_HIP, std::string("pack: ") + hipGetErrorString(e)); }
+    *out = L;
+    return 0;
+}
+extern "C" void aha_linear_destroy(aha_linear* L) {
+    if (!L) return;
+    hipSetDevice(L->device);
+    hipDeviceSynchronize();
+    hipFree(L->w.p);
+    delete L;
+}
+extern "C" int aha_linear_split_k(aha_ctx* c, const aha_linear* L, int requested) {
+    if (!c || !L) return AHA_E_INVAL;
+    const int nc = L->w.KS / 8;
+    int S = requested < 1 ? 1 : requested;
+    if (S > nc) S = nc;
+    if (S > 16) S = 16;
+    return S;
+}
+extern "C" int aha_linear_forward(aha_ctx* c, const aha_linear* L, const void* x, int ldx, int M, int epilogue, int split_k, const void* bias,
+                                  void* out, int ldo, aha_hip_stream st_) {
+    if (!c || !L || !x || !out || M <= 0) return AHA_E_INVAL;
+    if (L->pairs != (epilogue == EPI_SWIGLU)) return fail(c, AHA_E_INVAL, "the SwiGLU epilogue needs a gate/up pair weight (and only it)");
+    if (epilogue < EPI_PARTIAL || epilogue > EPI_F32_RBF) return fail(c, AHA_E_INVAL, "unknown epilogue");
+    if (bias && epilogue != EPI_BF16) return fail(c, AHA_E_INVAL, "bias is supported by the bf16 epilogue only");
+    hipStream_t st = (hipStream_t)st_;
+    const int S = epilogue == EPI_PARTIAL ? aha_linear_split_k(c, L, split_k) : 1;
+    const int mmax = aha_gemm_ws_max_m(epilogue);
+    for (int m0 = 0; m0 < M; m0 += mmax) {
+        GemmWsArgs a = ws_args((const bf16*)x, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, L->w, S, epilogue == EPI_PARTIAL ? (float*)out : nullptr,
+                               ldo, epilogue == EPI_BF16 || epilogue == EPI_SWIGLU ? (bf16*)out : nullptr, ldo,
+                               epilogue == EPI_F32_RBF ? (float*)out : nullptr, ldo);
+        a.bias = (const bf16*)bias;
+        HIPCHK(c, aha_gemm_ws(&a, epilogue, 4, st));
+    }
+    return 0;
+}
+extern "C" int aha_linear_tile_forward(aha_ctx* c, const void* x, int ldx, int M, const void* w, int ldw, int N, int K, const void* bias, int act,
+                                       const void* residual, int ldr, void* out, int ldo, aha_hip_stream st_) {
+    if (!c || !x || !w || !out || M <= 0 || N <= 0 || K <= 0) return AHA_E_INVAL;
+    if (K % 8 || ldx % 8 || ldw % 8) return fail(c, AHA_E_INVAL, "K and the leading dimensions must be multiples of 8");
+    if (act < ACT_NONE || act > ACT_QUICK_GELU) return fail(c, AHA_E_INVAL, "unknown activation");
+    HIPCHK(c, tile_gemm((const bf16*)x, ldx, M, (const bf16*)w, ldw, N, K, (bf16*)out, ldo, (const bf16*)bias, act, (const bf16*)residual, ldr,
+                        nullptr, 0, 0, (hipStream_t)st_));
+    return 0;
+}
+extern "C" int aha_rmsnorm_forward(aha_ctx* c, const void* x, int ldx, const void* w, void* out, int ldo, int M, int H, float eps, aha_hip_stream st) {
+    if (!c || !x || !w || !out) return AHA_E_INVAL;
+    HIPCHK(c, aha_rmsnorm((const bf16*)x, ldx, (const bf16*)w, (bf16*)out, ldo, M, H, eps, (hipStream_t)st));
+    return 0;
+}
+extern "C" int aha_resid_rmsnorm_forward(aha_ctx* c, const float* partial, int S, void* h, const void* w, void* xn, int M, int H, float eps,
+                                         aha_hip_stream st) {
+    if (!c || !partial || !h || !w || !xn || S < 1 || S > 16) return AHA_E_INVAL;
+    ResidNormArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.partial = partial; ra.S = S; ra.slab_stride = (long)M * H; ra.ldp = H;
+    ra.h = (bf16*)h; ra.ldh = H; ra.w = (const bf16*)w; ra.xn = (bf16*)xn; ra.ldx = H; ra.H = H; ra.eps = eps;
+    HIPCHK(c, aha_resid_norm(&ra, M, (hipStream_t)st));
+    return 0;
+}
+extern "C" int aha_heads_forward(aha_ctx* c, const void* hidden, int ld, int rows, float* scores, float* raw, aha_hip_stream st) {
+    if (!c || !hidden || (!scores && !raw) || !c->heads_w) return AHA_E_INVAL;
+    HIPCHK(c, aha_heads((const bf16*)hidden, ld, 0, 1, rows, c->heads_w, c->d.hidden, scores, raw, c->bar_err, (hipStream_t)st));
+    return 0;
+}
+
+// upload a descriptor built outside aha_lm_step through the same fenced pinned ring
+static int upload_desc(aha_ctx* c, const StepDesc& sd, hipStream_t st) {
+    const int si = c->sd_slot;
+    c->sd_slot = (si + 1) % aha_ctx::SD_SLOTS;
+    if (c->sd_ev[si]) HIPCHK(c, hipEventSynchronize(c->sd_ev[si]));
+    else HIPCHK(c, hipEventCreateWithFlags(&c->sd_ev[si], hipEventDisableTiming));
+    c->sd_pin[si] = sd;
+    HIPCHK(c, hipMemcpyAsync(c->sd_dev, c->sd_pin + si, sizeof(StepDesc), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->sd_ev[si], st));
+    return 0;
+}
+static void describe_current(const aha_stream* s, StreamStep* o) {
+    memset(o, 0, sizeof(*o));
+    o->k_base = s->k; o->v_base = s->v; o->cap = s->cap; o->ring_head = s->head; o->len_after = s->len; o->write_base = -1;
+    if (s->policy == AHA_CACHE_NONE || s->policy == AHA_CACHE_STATIC) { o->n_fixed = s->cap; o->ring_cap = 1; }
+    else if (s->policy == AHA_CACHE_SLIDING) { o->n_fixed = 0; o->ring_cap = s->W; }
+    else { o->n_fixed = s->sink; o->ring_cap = s->W - s->sink; }
+}
+
+// Operator-level attention: T query rows per stream (bf16 [B][T][heads*head_dim], already rotated) against the streams' caches
+// AS THEY ARE (the rows' own K/V must already be in the cache, e.g. through aha_cache_update), layer `layer`.
+// causal_off[b]: key j is visible to row t iff j <= causal_off[b] + t; null = the trailing rule (seq_length - T).
+extern "C" int aha_attention_forward(aha_ctx* c, aha_stream* const* streams, int B, const void* q, int T, int layer, const int* causal_off,
+                                     int split_len, void* out, aha_hip_stream st_) {
+    if (!c || !streams || !q || !out || B <= 0 || B > AHA_MAX_B || T <= 0) return AHA_E_INVAL;
+    const aha_model_desc& d = c->d;
+    if (layer < 0 || layer >= d.layers) return fail(c, AHA_E_RANGE, "layer out of range");
+    if (B * T > d.max_step_tokens) return fail(c, AHA_E_RANGE, "B*T > max_step_tokens");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    StepDesc sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.B = B; sd.T = T;
+    int max_lk = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!streams[b] || streams[b]->ctx != c) return fail(c, AHA_E_INVAL, "bad stream handle");
+        if (streams[b]->len <= 0) return fail(c, AHA_E_INVAL, "empty cache");
+        describe_current(streams[b], &sd.s[b]);
+        sd.s[b].causal_off = causal_off ? causal_off[b] : streams[b]->len - T;
+        max_lk = streams[b]->len > max_lk ? streams[b]->len : max_lk;
+    }
+    int rc = upload_desc(c, sd, st);
+    if (rc) return rc;
+    int sl = split_len > 0 ? round_up(split_len, 64) : (c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256);
+    int ns = ceil_div(max_lk, sl);
+    if (ns > 16) { sl = round_up(ceil_div(max_lk, 16), 64); ns = ceil_div(max_lk, sl); }
+    const int QD = d.heads * d.head_dim;
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const bf16*)q; a.q_bs = (long)T * QD; a.ldq = QD;
+    a.out = (bf16*)out; a.o_bs = (long)T * QD; a.ldo = QD;
+    a.part_o = c->part_o; a.part_ml = c->part_ml;
+    a.T = T; a.G = d.heads / d.kv_heads; a.Hkv = d.kv_heads; a.split_len = sl; a.n_splits = ns < 1 ? 1 : ns;
+    a.scale = 1.0f / sqrtf((float)d.head_dim); a.layer = layer;
+    HIPCHK(c, aha_attention(&a, c->sd_dev, B, d.head_dim, st));
+    return 0;
+}
+
+// Operator-level Cache.update(key_states, value_states, layer_idx, cache_kwargs) of the reference's cache classes
+// (test/sink_cache.py:74-164, test/sliding_window_cache.py:17-44, test/static_cache.py:18-36): new K/V bf16 [kv_heads][T][head_dim]
+// (already rotated).  Like the reference, layer 0's call advances the bookkeeping (seen tokens, eviction, positions) and the
+// other layers of the same step must follow in order; each call re-rotates that layer's kept keys (SinkCache) and appends.
+// out_k / out_v (optional): the (K, V) the reference's update() returns, bf16 [kv_heads][seq_length][head_dim] in logical order
+// - for a frozen TrulyStaticCache the stored prefix only.
+extern "C" int aha_cache_update(aha_ctx* c, aha_stream* s, int layer, const void* k_new, const void* v_new, int T, void* out_k, void* out_v,
+                                aha_hip_stream st_) {
+    if (!c || !s || s->ctx != c || !k_new || !v_new || T <= 0) return AHA_E_INVAL;
+    const aha_model_desc& d = c->d;
+    if (layer < 0 || layer >= d.layers) return fail(c, AHA_E_RANGE, "layer out of range");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    struct { StreamStep& ss; int& T; int& next_layer; bool& valid; } op{s->op_ss, s->op_T, s->op_next_layer, s->op_valid};
+    if (layer == 0) {
+        const int sv[3] = {s->len, s->head, s->seen};
+        int rc = plan_stream(c, s, T, &op.ss);
+        if (!rc && op.ss.n_rerot > 0 && !c->rope_cos) rc = fail(c, AHA_E_INVAL, "rope table not set");
+        if (!rc && op.ss.n_rerot > 0 && s->W > c->n_pos) rc = fail(c, AHA_E_RANGE, "SinkCache window exceeds the RoPE table");
+        if (rc) { s->len = sv[0]; s->head = sv[1]; s->seen = sv[2]; op.valid = false; return rc; }
+        op.T = T; op.valid = true; op.next_layer = 0;
+    }
+    if (!op.valid || op.T != T || layer != op.next_layer)
+        return fail(c, AHA_E_INVAL, "aha_cache_update: layers of a step must be updated in order 0..L-1 with the same T");
+    op.next_layer = layer + 1;
+    const bf16 *rc_ = nullptr, *rs_ = nullptr;
+    if (op.ss.n_rerot > 0) {
+        const auto key = std::make_tuple(s->W, s->sink, T);
+        if (!c->rerot.count(key)) {
+            const int rows = s->W - s->sink - T;
+            bf16 *pc, *ps;
+            int rc;
+            if ((rc = dalloc(c, &pc, (size_t)rows * d.head_dim)) || (rc = dalloc(c, &ps, (size_t)rows * d.head_dim))) return rc;
+            HIPCHK(c, aha_rerot_table(c->rope_cos, c->rope_sin, d.head_dim, s->sink, T, rows, pc, ps, st));
+            c->rerot[key] = {pc, ps};
+        }
+        rc_ = c->rerot[key].first; rs_ = c->rerot[key].second;
+    }
+    HIPCHK(c, aha_cache_update_layer(&op.ss, layer, d.kv_heads, d.head_dim, T, (const bf16*)k_new, (const bf16*)v_new, rc_, rs_, st));
+    if (out_k) { int rc = aha_stream_export_kv(c, s, layer, 0, out_k, st_); if (rc) return rc; }
+    if (out_v) { int rc = aha_stream_export_kv(c, s, layer, 1, out_v, st_); if (rc) return rc; }
+    return 0;
+}
+
+// fast_greedy_generate (models/modeling_live.py:64-90) + the token hand-back of _generate_response (test/inference.py:264-281):
+// greedy decode from `first_ids` (the stream-generation prompt) against the stream's cache, at most max_new_tokens single-token
+// steps, stopping after EOS.  argmax -> embedding row -> next step stay on the device (the id never travels through the host on
+// the data path); the host only polls the 8-byte id behind each step to honour the early stop exactly - this call therefore
+// blocks until the response is complete.  repetition_penalty > 0: RepetitionPenaltyLogitsProcessor over `history` (device
+// int64 [history_cap], *history_len entries; generated non-EOS ids are appended, as the reference's generated_token_ids list).
+extern "C" int aha_generate_greedy(aha_ctx* c, aha_stream* s, const int64_t* first_ids, int n_first, int max_new_tokens, int64_t eos_token_id,
+                                   float repetition_penalty, int64_t* history, int history_cap, int* history_len, int64_t* out_ids_host,
+                                   int* out_count, aha_hip_stream st_) {
+    if (!c || !s || !first_ids || n_first <= 0 || max_new_tokens <= 0 || !out_ids_host || !out_count) return AHA_E_INVAL;
+    if (!c->embed) return fail(c, AHA_E_NOENT, "model.embed_tokens.weight was not loaded");
+    if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
+    const bool pen = repetition_penalty > 0.f;
+    if (pen && (!history || !history_len || history_cap <= 0 || *history_len < 0 || *history_len > history_cap))
+        return fail(c, AHA_E_INVAL, "repetition penalty needs a history buffer");
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int H = d.hidden, V = d.vocab;
+    if (n_first > d.max_step_tokens) return fail(c, AHA_E_RANGE, "prompt longer than max_step_tokens");
+    int rc;
+    if (!c->gen_tok) {
+        if ((rc = dalloc(c, &c->gen_tok, 1)) || (rc = dalloc(c, &c->gen_nhist, 1)) || (rc = dalloc(c, &c->gen_emb, (size_t)d.max_step_tokens * H))) return rc;
+        if (hipHostMalloc((void**)&c->gen_pin, sizeof(long), hipHostMallocDefault) != hipSuccess) return fail(c, AHA_E_NOMEM, "hipHostMalloc failed");
+        HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev, hipEventDisableTiming));
+    }
+    if (c->gen_cap < max_new_tokens || (pen && c->gen_cap < history_cap)) {
+        const int cap = max_new_tokens > history_cap ? max_new_tokens : history_cap;
+        if ((rc = dalloc(c, &c->gen_out, (size_t)cap)) || (rc = dalloc(c, &c->gen_tmp, (size_t)cap))) return rc;
+        c->gen_cap = cap;
+    }
+    if (pen) HIPCHK(c, hipMemcpyAsync(c->gen_nhist, history_len, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, aha_embed_gather((const long*)first_ids, n_first, c->embed, H, V, c->gen_emb, H, st));
+    aha_stream* one[1] = {s};
+    int n = 0, T = n_first;
+    for (int i = 0; i < max_new_tokens; ++i) {
+        if ((rc = aha_lm_step(c, one, 1, c->gen_emb, T, c->graph_scores + 3 * (AHA_MAX_B - 1), nullptr, nullptr, st_))) return rc;
+        // lm_head on the last position -> fp32 logits (bf16-rounded, as a bf16 nn.Linear hands them on), penalty, argmax
+        if ((rc = ws_gemm(c, -1, c->xn + (size_t)(T - 1) * H, T * H, 1, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, c->logits, V, st))) return rc;
+        if (pen) HIPCHK(c, aha_repetition_penalty(c->logits, V, (const long*)history, c->gen_nhist, repetition_penalty, c->gen_tmp, st));
+        HIPCHK(c, aha_argmax(c->logits, V, V, 1, c->gen_tok, st));
+        HIPCHK(c, aha_generation_bookkeep(c->gen_tok, (long)eos_token_id, (long*)history, c->gen_nhist, history_cap, pen ? 1 : 0, c->gen_out, i, st));
+        HIPCHK(c, aha_embed_gather(c->gen_tok, 1, c->embed, H, V, c->gen_emb, H, st));       // next step's input, no host in between
+        HIPCHK(c, hipMemcpyAsync(c->gen_pin, c->gen_tok, sizeof(long), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipEventRecord(c->gen_ev, st));
+        HIPCHK(c, hipEventSynchronize(c->gen_ev));
+        const long tok = *c->gen_pin;
+        out_ids_host[n++] = tok;
+        if (pen && tok != eos_token_id && *history_len < history_cap) ++*history_len;
+        T = 1;
+        if (tok == eos_token_id) break;
+    }
+    *out_count = n;
     return 0;
 }
 

@@ -151,6 +151,19 @@ __global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, const
 // In the ring layout kept keys do not move, so this is the ONLY per-step traffic on old keys.
 // grid: (key blocks, layers*Hkv, B); block 256 threads = (256 / (D/8)) keys x D/8 items.
 // ---------------------------------------------------------------------------------------------
+template <int HALF>
+static __device__ __forceinline__ void rerotate_store4(bf16* kp, bf16x4 x1, bf16x4 x2, bf16x4 c1, bf16x4 s1, bf16x4 c2, bf16x4 s2) {
+    bf16x4 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a1 = bf2f(x1[e]), a2 = bf2f(x2[e]);
+        o1[e] = f2bf(rbf(a1 * bf2f(c1[e])) + rbf(-a2 * bf2f(s1[e])));
+        o2[e] = f2bf(rbf(a2 * bf2f(c2[e])) + rbf(a1 * bf2f(s2[e])));
+    }
+    *reinterpret_cast<bf16x4*>(kp) = o1;
+    *reinterpret_cast<bf16x4*>(kp + HALF) = o2;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __restrict__ sdp, unsigned stream_mask,
                                                             const bf16* __restrict__ rcos, const bf16* __restrict__ rsin,
@@ -168,15 +181,39 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
     const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
     const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d), s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
     const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF), s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
-    bf16x4 o1, o2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float a1 = bf2f(x1[e]), a2 = bf2f(x2[e]);
-        o1[e] = f2bf(rbf(a1 * bf2f(c1[e])) + rbf(-a2 * bf2f(s1[e])));
-        o2[e] = f2bf(rbf(a2 * bf2f(c2[e])) + rbf(a1 * bf2f(s2[e])));
+    rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
+}
+
+// Operator-level Cache.update of ONE layer (aha_cache_update): the same ring addressing and the same re-rotation arithmetic
+// as the fused step (qkv_finish_kernel's K/V store + sink_rerotate_kernel), with the step described by value.
+// grid: (max(n_rerot, T) key blocks, Hkv); new K/V: bf16 [Hkv][T][D] (already rotated, as the reference's attention hands
+// them to Cache.update, test/sink_cache.py:74-80).
+template <int D>
+__global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, int layer, int Hkv, int T, const bf16* __restrict__ knew,
+                                                                 const bf16* __restrict__ vnew, const bf16* __restrict__ rcos,
+                                                                 const bf16* __restrict__ rsin) {
+    constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
+    const int hk = blockIdx.y;
+    const int key = blockIdx.x * KPB + threadIdx.x / IPK;
+    const int d = (threadIdx.x % IPK) * 4;
+    const long lo = ((long)layer * Hkv + hk) * ss.cap;
+    if (key < ss.n_rerot) {                                  // kept window keys: re-rotate in place
+        bf16* kp = ss.k_base + (lo + phys_slot(ss, ss.n_fixed + key)) * D + d;
+        const long trow = (long)(ss.rerot_row0 + key) * D;
+        const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
+        const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d), s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
+        const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF), s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+        rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
     }
-    *reinterpret_cast<bf16x4*>(kp) = o1;
-    *reinterpret_cast<bf16x4*>(kp + HALF) = o2;
+    if (key < ss.write_count && ss.write_base >= 0) {        // new tokens: append (distinct slots from the kept keys)
+        const long slot = lo + phys_slot(ss, ss.write_base + key);
+        const bf16* ks = knew + ((long)hk * T + key) * D + d;
+        const bf16* vs = vnew + ((long)hk * T + key) * D + d;
+        *reinterpret_cast<bf16x4*>(ss.k_base + slot * D + d) = *reinterpret_cast<const bf16x4*>(ks);
+        *reinterpret_cast<bf16x4*>(ss.k_base + slot * D + d + HALF) = *reinterpret_cast<const bf16x4*>(ks + HALF);
+        *reinterpret_cast<bf16x4*>(ss.v_base + slot * D + d) = *reinterpret_cast<const bf16x4*>(vs);
+        *reinterpret_cast<bf16x4*>(ss.v_base + slot * D + d + HALF) = *reinterpret_cast<const bf16x4*>(vs + HALF);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +453,31 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     }
 }
 
+// RepetitionPenaltyLogitsProcessor on one logits row (transformers logits_process.py; used by fast_greedy_generate,
+// models/modeling_live.py:73-78): score = gather(logits, ids); score = score < 0 ? score * p : score / p; scatter back.
+// Two phases so that duplicate ids all read the ORIGINAL value (gather-then-scatter semantics).  One block.
+__global__ __launch_bounds__(1024) void repetition_penalty_kernel(float* __restrict__ logits, int V, const long* __restrict__ hist,
+                                                                  const int* __restrict__ n_hist, float penalty, float* __restrict__ tmp) {
+    const int n = *n_hist;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        long id = hist[i]; if (id < 0) id = 0; if (id > V - 1) id = V - 1;
+        const float sc = logits[id];
+        tmp[i] = sc < 0.f ? sc * penalty : sc / penalty;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        long id = hist[i]; if (id < 0) id = 0; if (id > V - 1) id = V - 1;
+        logits[id] = tmp[i];
+    }
+}
+// generated_token_ids.append(tok) unless tok is EOS (modeling_live.py:81-82); also mirrors the token for the host poll.
+__global__ void generation_bookkeep_kernel(const long* __restrict__ tok, long eos, long* __restrict__ hist, int* __restrict__ n_hist, int cap,
+                                           int use_hist, long* __restrict__ out_ids, int i) {
+    const long t = *tok;
+    out_ids[i] = t;
+    if (use_hist && t != eos && *n_hist < cap) { hist[*n_hist] = t; *n_hist = *n_hist + 1; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -460,6 +522,27 @@ hipError_t aha_rerot_table(const bf16* cosb, const bf16* sinb, int D, int sink, 
     const long total = (long)rows * D;
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(rerot_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cosb, sinb, D, sink, T, rows, rc, rs);
+    return hipGetLastError();
+}
+hipError_t aha_cache_update_layer(const StreamStep* ss, int layer, int Hkv, int D, int T, const bf16* knew, const bf16* vnew,
+                                   const bf16* rcos, const bf16* rsin, hipStream_t st) {
+    const int n = ss->n_rerot > ss->write_count ? ss->n_rerot : ss->write_count;
+    if (n <= 0) return hipSuccess;
+    if (D == 64) {
+        const int kpb = 256 / (64 / 8);
+        hipLaunchKernelGGL((cache_update_layer_kernel<64>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin);
+    } else if (D == 128) {
+        const int kpb = 256 / (128 / 8);
+        hipLaunchKernelGGL((cache_update_layer_kernel<128>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t aha_repetition_penalty(float* logits, int V, const long* hist, const int* n_hist, float penalty, float* tmp, hipStream_t st) {
+    hipLaunchKernelGGL(repetition_penalty_kernel, dim3(1), dim3(1024), 0, st, logits, V, hist, n_hist, penalty, tmp);
+    return hipGetLastError();
+}
+hipError_t aha_generation_bookkeep(const long* tok, long eos, long* hist, int* n_hist, int cap, int use_hist, long* out_ids, int i, hipStream_t st) {
+    hipLaunchKernelGGL(generation_bookkeep_kernel, dim3(1), dim3(1), 0, st, tok, eos, hist, n_hist, cap, use_hist, out_ids, i);
     return hipGetLastError();
 }
 hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H,

@@ -64,7 +64,30 @@ SYMBOLS = [
     ("aha_lm_last_step_work", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("aha_lm_last_gemm_time", _I, [_P, _I, C.POINTER(_F), C.POINTER(_I), C.POINTER(C.c_double)]),
     ("aha_version", C.c_char_p, []),
+    ("aha_lm_logits_all", _I, [_P, _P, _P]),
+    ("aha_generate_greedy", _I, [_P, _P, _P, _I, _I, C.c_int64, _F, _P, _I, C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I), _P]),
+    ("aha_linear_create", _I, [_P, _P, _P, _I, _I, C.POINTER(_P), _P]),
+    ("aha_linear_destroy", None, [_P]),
+    ("aha_linear_split_k", _I, [_P, _P, _I]),
+    ("aha_linear_forward", _I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P]),
+    ("aha_linear_tile_forward", _I, [_P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P]),
+    ("aha_rmsnorm_forward", _I, [_P, _P, _I, _P, _P, _I, _I, _I, _F, _P]),
+    ("aha_resid_rmsnorm_forward", _I, [_P, _P, _I, _P, _P, _P, _I, _I, _F, _P]),
+    ("aha_heads_forward", _I, [_P, _P, _I, _I, _P, _P, _P]),
+    ("aha_cache_update", _I, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    ("aha_attention_forward", _I, [_P, C.POINTER(_P), _I, _P, _I, _I, C.POINTER(_I), _I, _P, _P]),
+    ("aha_lm_debug_tap", _I, [_P, _I, _P, _P]),
+    ("aha_comm_unique_id", _I, [_P, C.c_size_t]),
+    ("aha_comm_init_rank", _I, [_P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),
+    ("aha_comm_size", _I, [_P]),
+    ("aha_comm_rank", _I, [_P]),
+    ("aha_allgather_scores", _I, [_P, _P, _I, _P, _P]),
+    ("aha_comm_destroy", None, [_P]),
+    ("aha_comm_last_error", C.c_char_p, []),
 ]
+EPI_SPLITK_F32, EPI_BF16, EPI_SWIGLU, EPI_F32 = 0, 1, 2, 3
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2, 3
+COMM_ID_BYTES = 128
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

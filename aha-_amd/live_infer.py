@@ -223,28 +223,11 @@ class LiveInferForBenchmark:
 
     # ---- models/modeling_live.py:64-90 (fast_greedy_generate) + test/inference.py:264-281 ----------
     def _generate_response(self):
+        """fast_greedy_generate runs inside the runtime (aha_generate_greedy): argmax -> embedding -> next single-token step
+        stay on the device, the host only reads back each 8-byte token id to stop at EOS."""
         self.last_ids = self._added_stream_generation_ids
-        inputs_embeds = self.rt.embed_tokens(self.last_ids).view(1, -1, self.hidden_size)
-        output_ids: List[int] = []
-        for _ in range(self.max_new_tokens):
-            self.rt.lm_step([self.past_key_values], inputs_embeds)
-            if self.repetition_penalty is not None:
-                logits, _ = self.rt.logits_last(1)
-                if len(self.generated_token_ids) > 0:    # RepetitionPenaltyLogitsProcessor
-                    idx = torch.tensor(self.generated_token_ids, device=self.device)[None]
-                    sc = torch.gather(logits, 1, idx)
-                    sc = torch.where(sc < 0, sc * self.repetition_penalty, sc / self.repetition_penalty)
-                    logits = logits.scatter(1, idx, sc)
-                tok = int(logits.argmax(dim=-1).item())
-                if tok != self.eos_token_id:             # special tokens should not be penalized
-                    self.generated_token_ids.append(tok)
-            else:
-                _, am = self.rt.logits_last(1, want_logits=False)
-                tok = int(am.item())
-            output_ids.append(tok)
-            if tok == self.eos_token_id:
-                break
-            inputs_embeds = self.rt.embed_tokens(torch.tensor([[tok]], device=self.device)).view(1, 1, self.hidden_size)
+        output_ids = self.rt.generate_greedy(self.past_key_values, self.last_ids, self.max_new_tokens, self.eos_token_id,
+                                             self.repetition_penalty, self.generated_token_ids)
         if not self.remove_assistant_turns:
             self.last_ids = torch.tensor([[output_ids[-1]]], device=self.device)
         else:

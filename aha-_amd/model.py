@@ -10,9 +10,10 @@ VideoHeadLiveLlavaQwenForCausalLM + LiveMixin that the drivers use
 
 `past_key_values` is one cache object (B == 1) or a list of B cache objects from aha_amd.cache
 (SinkCache / SlidingWindowCache / TrulyStaticCache / DynamicCache); None creates a DynamicCache,
-like transformers does.  Deviation, on purpose: `logits` covers the LAST position only
-([B,1,V]) and is computed on first access - the reference materialises lm_head over all T
-positions every frame (53 GFLOP + 30 MB that the frame loop never reads).
+like transformers does.  `logits` is computed on first access; by default it covers the LAST position only
+([B,1,V]) - the reference materialises lm_head over all T positions every frame (53 GFLOP + 30 MB that the
+frame loop never reads); LiveLlavaModel(rt, all_position_logits=True) returns the
+reference's full [B,T,V] (aha_lm_logits_all).
 """
 from __future__ import annotations
 
@@ -38,19 +39,27 @@ class VideoHeadCausalLMOutputWithPast:
     uncertainty: Optional[torch.Tensor] = None            # fp32 [B,T,1], log-variance
     _rt: Any = None
     _B: int = 0
+    _T: int = 0
+    _all_positions: bool = False
     _logits: Optional[torch.Tensor] = None
 
     @property
     def logits(self) -> torch.Tensor:
+        """fp32 [B,1,V] (last position; what the drivers read), or [B,T,V] like the reference's forward
+        (video_head_live_llava_qwen.py:175) when the model was built with all_position_logits=True.  Computed on first access."""
         if self._logits is None:
-            lg, _ = self._rt.logits_last(self._B)
-            self._logits = lg.view(self._B, 1, -1)
+            if self._all_positions:
+                self._logits = self._rt.logits_all(self._B, self._T)
+            else:
+                lg, _ = self._rt.logits_last(self._B)
+                self._logits = lg.view(self._B, 1, -1)
         return self._logits
 
 
 class LiveLlavaModel:
-    def __init__(self, runtime: Runtime):
+    def __init__(self, runtime: Runtime, all_position_logits: bool = False):
         self.rt = runtime
+        self.all_position_logits = all_position_logits
         self.config = runtime.cfg
         self.device = runtime.device
 
@@ -93,6 +102,6 @@ class LiveLlavaModel:
         return VideoHeadCausalLMOutputWithPast(
             past_key_values=caches[0] if not isinstance(past_key_values, (list, tuple)) else caches,
             informative_logits=raw[..., 0:2].contiguous(), relevance_logits=torch.sigmoid(raw[..., 2:3]),
-            uncertainty=raw[..., 3:4].contiguous(), _rt=self.rt, _B=B)
+            uncertainty=raw[..., 3:4].contiguous(), _rt=self.rt, _B=B, _T=T, _all_positions=self.all_position_logits)
 
     forward = __call__

@@ -295,6 +295,102 @@ class Runtime:
         self._chk(self.lib.aha_lm_logits_last(self.ctx, lg.data_ptr() if lg is not None else None, am.data_ptr(), _cur_stream()))
         return lg, am
 
+    def logits_all(self, B: int, T: int) -> torch.Tensor:
+        """lm_head over every position of the last step: fp32 [B,T,V] (video_head_live_llava_qwen.py:175)."""
+        lg = torch.empty((B * T, self.cfg.lm.vocab_size), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.aha_lm_logits_all(self.ctx, lg.data_ptr(), _cur_stream()))
+        return lg.view(B, T, -1)
+
+    def generate_greedy(self, stream: Stream, first_ids: torch.Tensor, max_new_tokens: int, eos_token_id: int,
+                        repetition_penalty: Optional[float] = None, generated_token_ids: Optional[list] = None) -> List[int]:
+        """fast_greedy_generate (models/modeling_live.py:64-90): returns the new token ids (the last one is EOS unless the
+        limit was hit) and, with a repetition penalty, appends the non-EOS ones to `generated_token_ids` like the reference."""
+        ids = first_ids.to(device=self.device, dtype=torch.long).contiguous().view(-1)
+        out = (C.c_int64 * max_new_tokens)()
+        n = C.c_int(0)
+        pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
+        hist, hlen = None, C.c_int(0)
+        if pen > 0:
+            prev = list(generated_token_ids or [])
+            hist = torch.zeros((len(prev) + max_new_tokens,), dtype=torch.long, device=self.device)
+            if prev:
+                hist[:len(prev)] = torch.tensor(prev, dtype=torch.long)
+            hlen = C.c_int(len(prev))
+        self._chk(self.lib.aha_generate_greedy(self.ctx, stream.handle, ids.data_ptr(), ids.numel(), max_new_tokens, int(eos_token_id), pen,
+                                               hist.data_ptr() if hist is not None else None, hist.numel() if hist is not None else 0,
+                                               C.byref(hlen), out, C.byref(n), _cur_stream()))
+        toks = [int(out[i]) for i in range(n.value)]
+        if pen > 0 and generated_token_ids is not None:
+            generated_token_ids.extend(t for t in toks if t != eos_token_id)
+        return toks
+
+    # -- operator level (include/aha_amd.h "operator level"): the step's kernels on caller tensors ------------------
+    def linear(self, w: torch.Tensor, w_up: Optional[torch.Tensor] = None) -> "Linear":
+        return Linear(self, w, w_up)
+
+    def linear_tile(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x, w = x.contiguous(), w.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_linear_tile_forward(self.ctx, x.data_ptr(), K, M, w.data_ptr(), K, N, K,
+                                                   bias.data_ptr() if bias is not None else None, int(act),
+                                                   residual.data_ptr() if residual is not None else None, N, out.data_ptr(), N, _cur_stream()))
+        return out
+
+    def rmsnorm(self, x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+        x = x.contiguous()
+        M, H = x.shape
+        out = torch.empty_like(x)
+        self._chk(self.lib.aha_rmsnorm_forward(self.ctx, x.data_ptr(), H, w.data_ptr(), out.data_ptr(), H, M, H, float(eps), _cur_stream()))
+        return out
+
+    def resid_rmsnorm(self, partial: torch.Tensor, h: torch.Tensor, w: torch.Tensor, eps: float):
+        """partial fp32 [S,M,H]; h bf16 [M,H] (updated in place: h += bf16(sum_s partial)); returns the normalised rows."""
+        S, M, H = partial.shape
+        assert h.is_contiguous() and partial.is_contiguous()
+        xn = torch.empty_like(h)
+        self._chk(self.lib.aha_resid_rmsnorm_forward(self.ctx, partial.data_ptr(), S, h.data_ptr(), w.data_ptr(), xn.data_ptr(), M, H,
+                                                     float(eps), _cur_stream()))
+        return xn
+
+    def heads(self, hidden: torch.Tensor):
+        hidden = hidden.contiguous()
+        n = hidden.shape[0]
+        sc = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        raw = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.aha_heads_forward(self.ctx, hidden.data_ptr(), hidden.shape[1], n, sc.data_ptr(), raw.data_ptr(), _cur_stream()))
+        return sc, raw
+
+    def cache_update(self, stream: Stream, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
+        """Cache.update(key_states, value_states, layer_idx, ...) of the reference's cache classes: k, v bf16 [1,Hkv,T,D] (or
+        [Hkv,T,D]); returns the (K, V) the reference's update() returns, [1,Hkv,L,D]."""
+        d = self.desc
+        k, v = k.reshape(d.kv_heads, -1, d.head_dim).contiguous(), v.reshape(d.kv_heads, -1, d.head_dim).contiguous()
+        T = k.shape[1]
+        self._chk(self.lib.aha_cache_update(self.ctx, stream.handle, int(layer_idx), k.data_ptr(), v.data_ptr(), T, None, None, _cur_stream()))
+        return stream.export_kv(layer_idx)[None], stream.export_kv(layer_idx, True)[None]
+
+    def attention(self, streams: Sequence[Stream], q: torch.Tensor, layer: int, causal_off: Optional[Sequence[int]] = None,
+                  split_len: int = 0) -> torch.Tensor:
+        """q bf16 [B,T,Hq*D] (rotated) over the streams' caches as they are -> bf16 [B,T,Hq*D]."""
+        q = q.contiguous()
+        B, T, _ = q.shape
+        out = torch.empty_like(q)
+        arr = (C.c_void_p * B)(*[s.handle for s in streams])
+        co = (C.c_int * B)(*causal_off) if causal_off is not None else None
+        self._chk(self.lib.aha_attention_forward(self.ctx, arr, B, q.data_ptr(), T, int(layer), co, int(split_len), out.data_ptr(), _cur_stream()))
+        return out
+
+    def debug_tap(self, which: str, B: int, T: int) -> torch.Tensor:
+        d = self.desc
+        idx, cols = {"h": (0, d.hidden), "xn": (1, d.hidden), "q_rot": (2, d.heads * d.head_dim), "attn_out": (3, d.heads * d.head_dim),
+                     "act": (4, d.inter)}[which]
+        out = torch.empty((B * T, cols), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_lm_debug_tap(self.ctx, idx, out.data_ptr(), _cur_stream()))
+        return out
+
     def last_step_work(self):
         wb, kb, fl = C.c_double(), C.c_double(), C.c_double()
         self._chk(self.lib.aha_lm_last_step_work(self.ctx, C.byref(wb), C.byref(kb), C.byref(fl)))
@@ -304,3 +400,41 @@ class Runtime:
         ms, n, by = C.c_float(), C.c_int(), C.c_double()
         self._chk(self.lib.aha_lm_last_gemm_time(self.ctx, kind, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+
+class Linear:
+    """nn.Linear weight in the streaming (weight-read-once) layout; `w_up` makes a gate/up pair for the SwiGLU epilogue."""
+
+    def __init__(self, rt: Runtime, w: torch.Tensor, w_up: Optional[torch.Tensor] = None):
+        self.rt, self.N, self.K = rt, w.shape[0], w.shape[1]
+        w = w.to(device=rt.device, dtype=torch.bfloat16).contiguous()
+        wu = w_up.to(device=rt.device, dtype=torch.bfloat16).contiguous() if w_up is not None else None
+        h = C.c_void_p()
+        rt._chk(rt.lib.aha_linear_create(rt.ctx, w.data_ptr(), wu.data_ptr() if wu is not None else None, self.N, self.K, C.byref(h), _cur_stream()))
+        self.handle, self.pairs = h, wu is not None
+
+    def __call__(self, x: torch.Tensor, epilogue: int = _l.EPI_BF16, split_k: int = 1, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        x = x.contiguous()
+        M = x.shape[0]
+        rt = self.rt
+        if epilogue == _l.EPI_SPLITK_F32:
+            S = rt.lib.aha_linear_split_k(rt.ctx, self.handle, split_k)
+            out = torch.empty((S, M, self.N), dtype=torch.float32, device=rt.device)
+        elif epilogue == _l.EPI_F32:
+            out = torch.empty((M, self.N), dtype=torch.float32, device=rt.device)
+        else:
+            out = torch.empty((M, self.N), dtype=torch.bfloat16, device=rt.device)
+        rt._chk(rt.lib.aha_linear_forward(rt.ctx, self.handle, x.data_ptr(), x.shape[1], M, int(epilogue), int(split_k),
+                                          bias.data_ptr() if bias is not None else None, out.data_ptr(), self.N, _cur_stream()))
+        return out
+
+    def close(self):
+        if self.handle is not None:
+            self.rt.lib.aha_linear_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -96,7 +96,9 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *   "attn_split_len"  keys per attention split (0 = heuristic)      "attn_tpw"  query tiles per wave of the dense (ViT) attention
  *   "tile_dma"        tiled-GEMM variant (0 register-staged, 1 auto, >= 2 forced variant id)
  *   "use_graph"       1: replay frozen static-cache steps from a captured HIP graph      "fuse_static" / "fuse_mlp"  experiments
- *   "time_gemm"       bit k: bracket GEMM kind k's launches with HIP events (aha_lm_last_gemm_time) */
+ *   "time_gemm"       bit k: bracket GEMM kind k's launches with HIP events (aha_lm_last_gemm_time); such steps are launched
+ *                     directly, not replayed from a graph, so the events are live
+ *   "layer_first" / "layer_count"  run decoder layers [first, first+count) only (0 = all): teacher-forced per-layer parity */
 int aha_ctx_set_tuning(aha_ctx* ctx, const char* key, int value);
 void aha_ctx_destroy(aha_ctx* ctx);
 const char* aha_last_error(aha_ctx* ctx);
@@ -172,6 +174,80 @@ int aha_lm_last_hidden_all(aha_ctx* ctx, void* out, aha_hip_stream st);
  * _encode_query :261 and fast_greedy_generate, models/modeling_live.py:64-90):
  * logits fp32 [B][vocab] (optional), argmax int64 [B] (optional) */
 int aha_lm_logits_last(aha_ctx* ctx, float* logits, int64_t* argmax, aha_hip_stream st);
+
+/* lm_head on EVERY position of the last step: outputs.logits fp32 [B*T][vocab] of the reference forward
+ * (video_head_live_llava_qwen.py:175).  Opt-in: the frame loop never reads it (53 GFLOP + 30 MB per frame), the model-API
+ * mirror (aha_amd.model) calls it only when `.logits_all` is asked for. */
+int aha_lm_logits_all(aha_ctx* ctx, float* logits, aha_hip_stream st);
+
+/* ---- response generation: fast_greedy_generate (models/modeling_live.py:64-90) as called by _generate_response
+ * (test/inference.py:264-281).  Greedy single-token steps from the `first_ids` prompt (device int64 [n_first]) against the
+ * stream's cache, at most max_new_tokens, stopping after eos_token_id.  argmax -> embedding -> next step stay on the device;
+ * the host polls the 8-byte token id behind each step to stop exactly at EOS, so this call BLOCKS until the response is done.
+ * repetition_penalty > 0 applies RepetitionPenaltyLogitsProcessor over `history` (device int64 [history_cap] holding
+ * *history_len ids; generated non-EOS ids are appended like the reference's generated_token_ids list) - <= 0 disables it.
+ * out_ids_host: host int64 [max_new_tokens]; *out_count: tokens produced (the last one is EOS unless the limit was hit). */
+int aha_generate_greedy(aha_ctx* ctx, aha_stream* s, const int64_t* first_ids_dev, int n_first, int max_new_tokens,
+                        int64_t eos_token_id, float repetition_penalty, int64_t* history_dev, int history_cap, int* history_len,
+                        int64_t* out_ids_host, int* out_count, aha_hip_stream st);
+
+/* ---- operator level: the pieces of the step as stand-alone operators on caller tensors.  The fused aha_lm_step is built
+ * from exactly these kernels; the parity tests drive them one by one on oracle-supplied inputs, and an integrator can replace
+ * individual modules of the reference with them. ------------------------------------------------------------------------ */
+/* nn.Linear weight [N][K] (bf16, device) repacked into the streaming layout; `w_up` non-null makes a gate/up pair for the
+ * SwiGLU epilogue (Qwen2MLP, transformers modeling_qwen2.py:35-49).  Set-up call (synchronises). */
+typedef struct aha_linear aha_linear;
+enum { AHA_EPI_SPLITK_F32 = 0,   /* out: fp32 [S][M][ldo] partial sums over S k-slices (S = aha_linear_split_k)  */
+       AHA_EPI_BF16 = 1,         /* out: bf16 [M][ldo] = bf16(x W^T (+ bias))                                    */
+       AHA_EPI_SWIGLU = 2,       /* out: bf16 [M][ldo] = bf16( bf16(silu(bf16(x Wg^T))) * bf16(x Wu^T) )         */
+       AHA_EPI_F32 = 3 };        /* out: fp32 [M][ldo] holding the bf16-rounded product (lm_head(...).float())   */
+int aha_linear_create(aha_ctx* ctx, const void* w, const void* w_up, int N, int K, aha_linear** out, aha_hip_stream st);
+void aha_linear_destroy(aha_linear* lin);
+int aha_linear_split_k(aha_ctx* ctx, const aha_linear* lin, int requested);   /* the S a request is clamped to */
+int aha_linear_forward(aha_ctx* ctx, const aha_linear* lin, const void* x, int ldx, int M, int epilogue, int split_k,
+                       const void* bias, void* out, int ldo, aha_hip_stream st);
+/* nn.Linear on a row-major weight through the tiled MFMA GEMM of the vision tower (SigLIP / CLIP layers, mm_projector):
+ * out = act(bf16(x W^T + bias)) (+ residual).  act: 0 none, 1 gelu_pytorch_tanh, 2 gelu (erf), 3 quick_gelu */
+int aha_linear_tile_forward(aha_ctx* ctx, const void* x, int ldx, int M, const void* w, int ldw, int N, int K, const void* bias,
+                            int act, const void* residual, int ldr, void* out, int ldo, aha_hip_stream st);
+/* Qwen2RMSNorm (modeling_qwen2.py:236-254) */
+int aha_rmsnorm_forward(aha_ctx* ctx, const void* x, int ldx, const void* w, void* out, int ldo, int M, int H, float eps,
+                        aha_hip_stream st);
+/* split-K reduce + residual add + RMSNorm: lin = bf16(sum_s partial[s]); h = bf16(h + lin) (in place); xn = w * norm(h) */
+int aha_resid_rmsnorm_forward(aha_ctx* ctx, const float* partial, int S, void* h, const void* w, void* xn, int M, int H,
+                              float eps, aha_hip_stream st);
+/* the three scoring heads + score post-ops on hidden rows (video_head_live_llava_qwen.py:185-188, test/inference.py:222-227):
+ * raw fp32 [rows][4] (optional), scores fp32 [rows][3] (optional) */
+int aha_heads_forward(aha_ctx* ctx, const void* hidden, int ld, int rows, float* scores, float* raw, aha_hip_stream st);
+/* Cache.update(key_states, value_states, layer_idx, cache_kwargs) of the reference's cache classes (test/sink_cache.py:74-164,
+ * test/sliding_window_cache.py:17-44, test/static_cache.py:18-36) on one stream: k_new / v_new bf16 [kv_heads][T][head_dim]
+ * (keys already rotated).  As in the reference, layer 0's call advances the bookkeeping and the remaining layers of the step
+ * follow in order.  out_k / out_v (optional): the (K, V) update() returns, bf16 [kv_heads][seq_length][head_dim]. */
+int aha_cache_update(aha_ctx* ctx, aha_stream* s, int layer_idx, const void* k_new, const void* v_new, int T, void* out_k,
+                     void* out_v, aha_hip_stream st);
+/* attention of T query rows per stream (bf16 [B][T][heads*head_dim], rotated) over the streams' caches as they are, layer
+ * `layer`; key j visible to row t iff j <= causal_off[b] + t (null: seq_length - T, the trailing-causal rule); split_len: keys
+ * per split (0 = default).  out: bf16 [B][T][heads*head_dim] */
+int aha_attention_forward(aha_ctx* ctx, aha_stream* const* streams, int B, const void* q, int T, int layer, const int* causal_off,
+                          int split_len, void* out, aha_hip_stream st);
+/* parity tap: a workspace of the last aha_lm_step.  which: 0 residual stream [M][hidden] (hidden state after the last executed
+ * layer), 1 normalised stream [M][hidden], 2 rotated queries, 3 attention output [M][heads*head_dim], 4 SwiGLU activation
+ * [M][inter] (2-4: the last executed layer; tuning "layer_first" / "layer_count" select it) */
+int aha_lm_debug_tap(aha_ctx* ctx, int which, void* out, aha_hip_stream st);
+
+/* ---- multi-GPU: the one collective of the path.  Streams are independent; ranks only exchange their score
+ * rows.  RCCL communicator from a unique id the host distributes (rank 0 calls aha_comm_unique_id, everyone
+ * aha_comm_init_rank).  The reference has no inference collective (utils/dist_utils.py:46-78 is training-only). */
+typedef struct aha_comm aha_comm;
+#define AHA_COMM_ID_BYTES 128
+int aha_comm_unique_id(void* id_out, size_t bytes);
+int aha_comm_init_rank(const void* id, size_t bytes, int nranks, int rank, int device, aha_comm** out);
+int aha_comm_size(const aha_comm* comm);
+int aha_comm_rank(const aha_comm* comm);
+/* local fp32 [rows][3] -> global fp32 [nranks][rows][3]; ncclAllGather on `st`, asynchronous */
+int aha_allgather_scores(aha_comm* comm, const float* local, int rows, float* global, aha_hip_stream st);
+void aha_comm_destroy(aha_comm* comm);
+const char* aha_comm_last_error(void);
 
 /* ---- introspection ------------------------------------------------------------------------- */
 /* algorithmic bytes / flops of the last aha_lm_step (SURVEY.md 8d accounting) */

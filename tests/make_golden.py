@@ -30,7 +30,7 @@ from aha_amd.config import preset  # noqa: E402
 from aha_amd.synth import make_frames, make_weights  # noqa: E402
 
 CACHE_STEPS = [20, 7, 7, 9, 7, 30, 7, 7, 7, 7, 5, 7, 7, 7]
-CACHE_W, CACHE_SINK, CACHE_D, CACHE_LAYERS, CACHE_HKV, CACHE_THETA = 64, 8, 32, 2, 2, 1e4
+CACHE_W, CACHE_SINK, CACHE_D, CACHE_LAYERS, CACHE_HKV, CACHE_THETA = 64, 8, 64, 2, 2, 1e4      # D = 64: the smallest head_dim the HIP LM kernels instantiate, so the same fixture also checks the device ring
 
 
 def bf16_bits(t: torch.Tensor) -> np.ndarray:

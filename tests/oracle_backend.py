@@ -64,3 +64,27 @@ class OracleBackedRuntime:
     def logits_last(self, B, want_logits=True):
         lg = torch.cat([o["logits"][:, -1] for o in self._last], 0)
         return (lg if want_logits else None), lg.argmax(-1)
+
+    def generate_greedy(self, stream, first_ids, max_new_tokens, eos_token_id, repetition_penalty=None, generated_token_ids=None):
+        """fast_greedy_generate (models/modeling_live.py:64-90) on the oracle."""
+        emb = self.embed_tokens(first_ids).view(1, -1, self.hidden_size)
+        out = []
+        for _ in range(max_new_tokens):
+            self.lm_step([stream], emb)
+            logits, am = self.logits_last(1)
+            if repetition_penalty is not None:
+                if generated_token_ids:
+                    idx = torch.tensor(generated_token_ids)[None]
+                    sc = torch.gather(logits, 1, idx)
+                    sc = torch.where(sc < 0, sc * repetition_penalty, sc / repetition_penalty)
+                    logits = logits.scatter(1, idx, sc)
+                tok = int(logits.argmax(-1).item())
+                if tok != eos_token_id and generated_token_ids is not None:
+                    generated_token_ids.append(tok)
+            else:
+                tok = int(am.item())
+            out.append(tok)
+            if tok == eos_token_id:
+                break
+            emb = self.embed_tokens(torch.tensor([[tok]])).view(1, 1, self.hidden_size)
+        return out
