@@ -22,7 +22,8 @@ with cos/sin; positions = ``cache.get_seq_length()`` + arange(T); attention mask
       the returned key length).  Equals "trailing" while the cache grows; once a sink or
       sliding window is full it lets a new token see later tokens of its own chunk.
 
-Pinned by tests/test_oracle_lm.py against local transformers Qwen2Model + DynamicCache.
+Pinned by tests/test_oracle_models.py against local transformers Qwen2Model + DynamicCache
+(live, and through tests/golden/qwen2_tiny_steps.npz).
 """
 from __future__ import annotations
 
@@ -63,25 +64,41 @@ class OracleLM:
         assert attn_semantics in ("trailing", "hf449_sdpa")
         self.attn_semantics = attn_semantics
         self.attn_impl = attn_impl
+        # PEFT LoRA adapters, UNMERGED as the reference runs them (PeftModel.from_pretrained, models/modeling_live.py:171-179;
+        # peft==0.12.0 lora.Linear.forward: result = base(x) + lora_B(lora_A(x)) * scaling, in the working dtype):
+        # {weight name: (A [r,in], B [out,r], scaling)}
+        self.lora: Dict[str, tuple] = {}
+
+    def attach_lora(self, adapters: Dict[str, tuple]) -> None:
+        self.lora = {k: (a.to(self.dtype), b.to(self.dtype), float(s)) for k, (a, b, s) in adapters.items()}
+
+    def _lin(self, x, name, bias=None):
+        y = F.linear(x, self.w[name], bias)
+        if name in self.lora:
+            a, b, s = self.lora[name]
+            y = y + F.linear(F.linear(x, a), b) * s
+        return y
 
     # -- embeddings ---------------------------------------------------------------
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
         return F.embedding(ids, self.w["model.embed_tokens.weight"])
 
     # -- one decoder layer ----------------------------------------------------------
-    def _attention(self, i, x, cos, sin, cache, L_before, static_frozen):
+    def _attention(self, i, x, cos, sin, cache, L_before, static_frozen, tr=None):
         c = self.c
         B, T, _ = x.shape
         p = f"model.layers.{i}.self_attn."
-        q = F.linear(x, self.w[p + "q_proj.weight"], self.w[p + "q_proj.bias"])
-        k = F.linear(x, self.w[p + "k_proj.weight"], self.w[p + "k_proj.bias"])
-        v = F.linear(x, self.w[p + "v_proj.weight"], self.w[p + "v_proj.bias"])
+        q = self._lin(x, p + "q_proj.weight", self.w[p + "q_proj.bias"])
+        k = self._lin(x, p + "k_proj.weight", self.w[p + "k_proj.bias"])
+        v = self._lin(x, p + "v_proj.weight", self.w[p + "v_proj.bias"])
         q = q.view(B, T, c.num_attention_heads, c.head_dim).transpose(1, 2)
         k = k.view(B, T, c.num_key_value_heads, c.head_dim).transpose(1, 2)
         v = v.view(B, T, c.num_key_value_heads, c.head_dim).transpose(1, 2)
         cu, su = cos.unsqueeze(1), sin.unsqueeze(1)
         q = (q * cu) + (rotate_half(q) * su)            # modeling_qwen2.py:128-129
         k = (k * cu) + (rotate_half(k) * su)
+        if tr is not None:
+            tr.update(q=q, k=k, v=v)                    # post-RoPE q/k and v, [B, heads, T, D]
         K, V = cache.update(k, v, i, {"sin": sin, "cos": cos})
         Lk = K.shape[-2]
         # visibility: key j visible to new token t iff j <= off + t
@@ -106,17 +123,22 @@ class OracleLM:
             aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
             o = torch.matmul(aw, Vr)
         o = o.transpose(1, 2).reshape(B, T, -1)
-        return F.linear(o, self.w[p + "o_proj.weight"])
+        if tr is not None:
+            tr.update(attn_out=o, K=K, V=V)
+        return self._lin(o, p + "o_proj.weight")
 
-    def _mlp(self, i, x):
+    def _mlp(self, i, x, tr=None):
         p = f"model.layers.{i}.mlp."
-        g = F.linear(x, self.w[p + "gate_proj.weight"])
-        u = F.linear(x, self.w[p + "up_proj.weight"])
-        return F.linear(F.silu(g) * u, self.w[p + "down_proj.weight"])
+        g = self._lin(x, p + "gate_proj.weight")
+        u = self._lin(x, p + "up_proj.weight")
+        a = F.silu(g) * u
+        if tr is not None:
+            tr.update(act=a)
+        return self._lin(a, p + "down_proj.weight")
 
     # -- the step -----------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, inputs_embeds: torch.Tensor, cache, want_logits: bool = False) -> dict:
+    def step(self, inputs_embeds: torch.Tensor, cache, want_logits: bool = False, trace: Optional[list] = None) -> dict:
         """inputs_embeds [B,T,H] in the working dtype; ``cache`` a policy from
         oracle.cache_policies (mutated in place).  Returns the fields of
         VideoHeadCausalLMOutputWithPast the driver consumes
@@ -132,12 +154,18 @@ class OracleLM:
         cos, sin = rope_cos_sin(pos, c.head_dim, c.rope_theta, self.dtype)
         for i in range(c.num_hidden_layers):
             p = f"model.layers.{i}."
+            tr = {"x_in": h} if trace is not None else None   # per-layer tensors for the teacher-forced parity tests
             r = h
             x = rms_norm(h, self.w[p + "input_layernorm.weight"], c.rms_norm_eps)
-            h = r + self._attention(i, x, cos, sin, cache, L_before, static_frozen)
+            h = r + self._attention(i, x, cos, sin, cache, L_before, static_frozen, tr)
             r = h
             x = rms_norm(h, self.w[p + "post_attention_layernorm.weight"], c.rms_norm_eps)
-            h = r + self._mlp(i, x)
+            if tr is not None:
+                tr.update(h_mid=h, x_mid=x)
+            h = r + self._mlp(i, x, tr)
+            if tr is not None:
+                tr["h_out"] = h
+                trace.append(tr)
         h = rms_norm(h, self.w["model.norm.weight"], c.rms_norm_eps)
         out = {"hidden": h, "past_key_values": cache}
         # video_head_live_llava_qwen.py:185-188

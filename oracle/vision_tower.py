@@ -19,7 +19,7 @@ transformers copy, transformers/models/siglip/modeling_siglip.py:116-358 (embedd
 :116-186, attention :251-308, MLP :312-324, layer :327-358): the llava tower returns the
 last executed encoder layer's hidden state with no post-layernorm and no pooling head.
 
-Pinned by tests/test_oracle_vision.py against local transformers SiglipVisionModel.
+Pinned by tests/test_oracle_models.py against local transformers SiglipVisionModel.
 """
 from __future__ import annotations
 
