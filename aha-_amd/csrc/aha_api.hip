@@ -31,7 +31,8 @@ struct LayerW {
 struct VLayerW {
     bf16 *ln1w, *ln1b, *wqkv, *bqkv, *wo, *bo, *ln2w, *ln2b, *w1, *b1, *w2, *b2;
 };
-enum { GK_QKV = 0, GK_O = 1, GK_GATEUP = 2, GK_DOWN = 3, GK_COUNT = 4 };
+enum { GK_QKV = 0, GK_O = 1, GK_GATEUP = 2, GK_DOWN = 3, GK_GEMMS = 4,      // the four weight-streaming GEMM kinds (split / wpb knobs)
+       GK_ATTN = 4, GK_REROT = 5, GK_COUNT = 6 };                         // timed kinds also cover cache attention and sink re-rotation
 
 struct aha_ctx {
     aha_model_desc d;
@@ -89,10 +90,10 @@ struct aha_ctx {
     bf16 *v_a0 = nullptr, *v_x = nullptr, *v_h = nullptr, *v_qkv = nullptr, *v_attn = nullptr, *v_f = nullptr,
          *v_p1 = nullptr, *v_p2 = nullptr;
     // tuning
-    int split[GK_COUNT] = {0, 0, 0, 0};
+    int split[GK_GEMMS] = {0, 0, 0, 0};
     // waves per workgroup per GEMM kind (measured: tools/tune_lm.py).  gate/up: 1184 wave-tasks as 237 five-wave workgroups
     // (one per CU on 237 CUs) instead of 148 eight-wave ones: each CU then ingests less than its ~43 GB/s ceiling.
-    int wpb[GK_COUNT] = {4, 4, 5, 8};
+    int wpb[GK_GEMMS] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
     int layer_first = 0, layer_count = 0;                   // tuning: run only decoder layers [first, first+count) (0 = all); parity taps
@@ -105,8 +106,8 @@ struct aha_ctx {
     // accounting of the last step
     double last_weight_bytes = 0, last_kv_bytes = 0, last_flops = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GK_COUNT];
-    int ev_used[GK_COUNT] = {0, 0, 0, 0};
-    double gk_bytes[GK_COUNT] = {0, 0, 0, 0};
+    int ev_used[GK_COUNT] = {0};
+    double gk_bytes[GK_COUNT] = {0};
     std::vector<void*> allocs;
 };
 
@@ -889,28 +890,34 @@ static GemmWsArgs ws_args(const bf16* X, int ldx, int M, int m0, int mrows, cons
     return a;
 }
 
+// HIP-event bracket of one timed launch group (tuning "time_gemm": bit k = kind k), on the launch stream
+static int timed_begin(aha_ctx* c, int kind, hipStream_t st) {
+    if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev[kind].push_back({a, b});
+    }
+    HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].first, st));
+    return 0;
+}
+static int timed_end(aha_ctx* c, int kind, double bytes, hipStream_t st) {
+    HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].second, st));
+    c->ev_used[kind]++;
+    c->gk_bytes[kind] += bytes;
+    return 0;
+}
+
 static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
                    bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
     const int mmax = aha_gemm_ws_max_m(epi);
     const bool timed = kind >= 0 && ((c->time_gemm >> kind) & 1);      // time_gemm: bit k = GEMM kind k
-    if (timed) {
-        if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
-            hipEvent_t a, b;
-            HIPCHK(c, hipEventCreate(&a));
-            HIPCHK(c, hipEventCreate(&b));
-            c->ev[kind].push_back({a, b});
-        }
-        HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].first, st));
-    }
+    if (timed) { if (int rc = timed_begin(c, kind, st)) return rc; }
     for (int m0 = 0; m0 < M; m0 += mmax) {
         GemmWsArgs a = ws_args(X, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, w, S, partial, ldp, out, ldo, outf, ldof);
         HIPCHK(c, aha_gemm_ws(&a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
     }
-    if (timed) {
-        HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].second, st));
-        c->ev_used[kind]++;
-        c->gk_bytes[kind] += w.bytes() * ceil_div(M, mmax);
-    }
+    if (timed) { if (int rc = timed_end(c, kind, w.bytes() * ceil_div(M, mmax), st)) return rc; }
     c->last_weight_bytes += w.bytes();
     c->last_flops += 2.0 * (double)w.n_tiles * 16.0 * (double)w.K * (double)M;
     return 0;
@@ -1012,7 +1019,15 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 }
             }
             auto tb = c->rerot[std::make_tuple(streams[b]->W, streams[b]->sink, T)];
+            const bool timed = (c->time_gemm >> GK_REROT) & 1;
+            if (timed) { if (int rc = timed_begin(c, GK_REROT, st)) return rc; }
             HIPCHK(c, aha_sink_rerotate(c->sd_dev, mask, B, nmax, tb.first, tb.second, d.layers, d.kv_heads, Dh, st));
+            if (timed) {
+                double by = 0;                               // algorithmic: every kept key of every layer read and written once
+                for (int b2 = 0; b2 < B; ++b2)
+                    if ((mask >> b2) & 1u) by += (double)sd.s[b2].n_rerot * d.layers * d.kv_heads * Dh * 2.0 * 2.0;
+                if (int rc = timed_end(c, GK_REROT, by, st)) return rc;
+            }
         }
     }
 
@@ -1071,7 +1086,14 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             a.part_o = c->part_o; a.part_ml = c->part_ml;
             a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
             a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
+            const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
+            if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
             HIPCHK(c, aha_attention(&a, c->sd_dev, B, Dh, st));
+            if (t_attn) {                                    // algorithmic: this layer's K and V of every stream read once
+                double by = 0;
+                for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;
+                if ((rc = timed_end(c, GK_ATTN, by, st))) return rc;
+            }
             // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
             const int So = pick_split(c, GK_O, w.o, M, 1);
             if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
@@ -1504,12 +1526,12 @@ extern "C" int aha_lm_last_step_work(aha_ctx* c, double* wb, double* kvb, double
 }
 
 extern "C" int aha_lm_last_gemm_time(aha_ctx* c, int kind, float* ms, int* launches, double* bytes) {
-    if (!c || kind < 0 || kind > GK_COUNT) return AHA_E_INVAL;
+    if (!c || kind < -1 || kind >= GK_COUNT) return AHA_E_INVAL;
     float total = 0.f;
     int n = 0;
     double by = 0;
     for (int k = 0; k < GK_COUNT; ++k) {
-        if (kind != GK_COUNT && kind != k) continue;
+        if (kind == -1 ? k >= GK_GEMMS : kind != k) continue;          // -1: the four GEMM kinds together
         for (int i = 0; i < c->ev_used[k]; ++i) {
             float t = 0.f;
             HIPCHK(c, hipEventSynchronize(c->ev[k][i].second));

@@ -396,7 +396,7 @@ class Runtime:
         self._chk(self.lib.aha_lm_last_step_work(self.ctx, C.byref(wb), C.byref(kb), C.byref(fl)))
         return wb.value, kb.value, fl.value
 
-    def last_gemm_time(self, kind: int = 4):
+    def last_gemm_time(self, kind: int = -1):
         ms, n, by = C.c_float(), C.c_int(), C.c_double()
         self._chk(self.lib.aha_lm_last_gemm_time(self.ctx, kind, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value

@@ -4,17 +4,23 @@
 A "step" = one pass of the hot path over one batch of synthetic input for every stream this rank
 owns: `--frames` uint8 frames per stream are encoded by the vision tower in one batch (the
 reference pre-encodes 32-frame batches, test/inference.py:181-185) and then scored frame by frame
-by the LM step against the stream's KV cache (the per-frame loop of test/inference.py:283-335; with the frozen static
-cache each step is replayed from a captured HIP graph, bit-identical to direct launches),
-ending when the [frames,3] score rows are host-visible.  N=1 workload = BASELINE.json configs[1]:
-SigLIP-L/14@336 + Qwen2-7B bf16, single stream, static KV cache.  With N>1 every rank runs its own
-independent stream(s) (weak scaling) and the per-step score rows are all-gathered with RCCL.
+by the LM step against the stream's KV cache (the per-frame loop of test/inference.py:283-335; each step is
+replayed from a captured HIP graph, bit-identical to direct launches), ending when the [frames,3] score rows
+are host-visible.  N=1 workload = BASELINE.json configs[1]: SigLIP-L/14@336 + Qwen2-7B bf16, single stream,
+static KV cache.  With N>1 every rank runs its own independent stream(s) (weak scaling) and the per-step score
+rows are all-gathered with RCCL.
+
+`--gpus N` with no WORLD_SIZE in the environment: this process launches the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`) BEFORE touching the GPU and relays rank 0's
+JSON line.  Under an external launcher (WORLD_SIZE set) `--gpus` must equal WORLD_SIZE.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,11 +28,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import aha_amd  # noqa: E402,F401
-from aha_amd.config import preset  # noqa: E402
-from aha_amd.synth import make_frames, make_token_ids, make_weights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16 dense ~2.5 PFLOP/s
 
 
 def parse():
@@ -42,17 +46,46 @@ def parse():
     p.add_argument("--sink", type=int, default=32)
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-side collective (rehearsal)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the secondary data (sink_w2048, eight_stream_sink, static batching)")
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
+    p.add_argument("--abi-allgather", action="store_true",
+                   help="also run the C-ABI collective (aha_allgather_scores: RCCL communicator from a unique id) and compare it with "
+                        "torch.distributed's; always on for a single rank under --force-dist")
+    p.add_argument("--dry-run-collective", action="store_true",
+                   help="launcher / rendezvous / all-gather plumbing only, on synthetic score rows: no GPU, no hot path, value = null")
     p.add_argument("--tile-dma", type=int, default=-1, help="experiment: force a tiled-GEMM variant in the vision tower")
     p.add_argument("--vit-cus", type=int, default=0,
                    help="experiment: restrict the vision stream to this many CUs (HIP CU mask, XCD-balanced)")
     p.add_argument("--lm-cus", type=int, default=-1,
                    help="with --vit-cus: CUs of the LM stream (-1 = the complement of the vision stream's, 0 = all)")
     return p.parse_args()
+
+
+def launch_ranks(a):
+    """--gpus N without an external launcher: start N ranks as children (never exec: this process has not touched the GPU and
+    does not need to), relay rank 0's JSON line, exit with the launcher's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:])
+        sys.exit(p.returncode or 1)
+    print(line)
+    sys.exit(0)
 
 
 def cu_masked_stream(first_cu, n_cus, total_cus):
@@ -73,16 +106,17 @@ def cu_masked_stream(first_cu, n_cus, total_cus):
 
 
 def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be
-    collected from inside the process being measured)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        for k in d["kernels"]:
-            if kernel_prefix in k["kernel"]:
-                return k["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (counters cannot be collected from
+    inside the process being measured)."""
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            for k in d["kernels"]:
+                if kernel_prefix in k["kernel"]:
+                    return k["hbm_bytes_per_launch"], name
+        except Exception:
+            pass
+    return None, None
 
 
 def host_cores():
@@ -132,14 +166,100 @@ def cpu_baseline(cfg, weights_cpu, frames_u8, prefix_ids, query_ids, cache, wind
             "sample": f"{done} frames (ViT 1 frame + LM step each, frame 0 carries the system prompt), oracle {str(dt_cpu).split('.')[-1]} sdpa on {cores} threads, {dt:.1f}s"}
 
 
+class Workload:
+    """B streams x F frames per step on one GPU: batched vision encode on a second HIP stream (double-buffered embeddings,
+    events both ways) while the LM scores the previous batch; every batch's encode and all of its LM steps are timed."""
+
+    def __init__(self, rt, cfg, dev, B, F, cache, window, sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream, gather=None):
+        self.rt, self.B, self.F, self.tf, self.H = rt, B, F, cfg.frame_num_tokens, cfg.lm.hidden_size
+        self.frames_all, self.main_stream, self.vit_stream, self.gather = frames_all, main_stream, vit_stream, gather
+        self.streams = [rt.open_stream(cache, window, sink, capacity=cfg.lm.max_position_embeddings) for _ in range(B)]
+        self.scores_host = torch.empty((F, B, 3), dtype=torch.float32).pin_memory()
+        self.scores_dev = torch.empty((F, B, 3), dtype=torch.float32, device=dev)
+        self.last_global = None
+        tf, H = self.tf, self.H
+        # stream prologue (untimed): query turn first (test/inference.py:294-298), then system prompt + frame 0
+        q = rt.embed_tokens(query_ids).view(1, -1, H).expand(B, -1, -1).contiguous()
+        rt.lm_step(self.streams, q)
+        emb0 = rt.visual_embed(frames_all[::F].contiguous()).view(B, tf, H)
+        pre = rt.embed_tokens(prefix_ids).view(1, -1, H).expand(B, -1, -1)
+        rt.lm_step(self.streams, torch.cat([pre, emb0], dim=1).contiguous())
+        self.emb_buf = [torch.empty((B * F * tf, H), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+        self.emb_ready = [torch.cuda.Event() for _ in range(2)]
+        self.emb_free = [torch.cuda.Event() for _ in range(2)]
+        for e in self.emb_free:
+            e.record(main_stream)
+
+    def encode(self, k):
+        with torch.cuda.stream(self.vit_stream):
+            self.vit_stream.wait_event(self.emb_free[k & 1])           # the LM is done with this slot
+            self.rt.visual_embed(self.frames_all, out=self.emb_buf[k & 1])
+            self.emb_ready[k & 1].record(self.vit_stream)
+
+    def run(self, n_steps):
+        B, F, tf, H = self.B, self.F, self.tf, self.H
+        with torch.cuda.stream(self.main_stream):
+            self.encode(0)
+            for k in range(n_steps):
+                if k + 1 < n_steps:
+                    self.encode(k + 1)
+                self.main_stream.wait_event(self.emb_ready[k & 1])
+                emb = self.emb_buf[k & 1].view(B, F, tf, H)
+                for i in range(F):
+                    self.scores_dev[i] = self.rt.lm_step(self.streams, emb[:, i].contiguous())
+                self.emb_free[k & 1].record(self.main_stream)
+                if self.gather is not None:
+                    self.last_global = self.gather(self.scores_dev)    # one collective per step on the [F, B, 3] score rows
+                self.scores_host.copy_(self.scores_dev, non_blocking=True)
+
+    def last_emb(self, n_steps):
+        return self.emb_buf[(n_steps - 1) & 1].view(self.B, self.F, self.tf, self.H)
+
+    def close(self):
+        for s in self.streams:
+            s.close()
+
+
+def timed_kind(rt, wl, emb, kind, n_steps=4, skip=1):
+    """HIP-event time of one launch kind on LM steps issued with nothing else in flight (direct launches: timed steps bypass
+    graph replay so the events are live).  Returns (ms, launch groups, algorithmic bytes)."""
+    rt.set_tuning("time_gemm", 1 << kind)
+    ms = by = 0.0
+    n = 0
+    F = emb.shape[1]
+    for i in range(n_steps + skip):
+        rt.lm_step(wl.streams, emb[:, i % F].contiguous())
+        torch.cuda.synchronize()
+        if i >= skip:
+            m, c, b = rt.last_gemm_time(kind)
+            ms, n, by = ms + m, n + c, by + b
+    rt.set_tuning("time_gemm", 0)
+    return ms, n, by
+
+
+def roofline_hbm(kernel, ms, n, by, traffic_prefix=None):
+    ach = (by / n) / ((ms / n) * 1e-3) / 1e9 if n and ms > 0 else None
+    traffic, src = pmc_traffic(traffic_prefix) if traffic_prefix else (None, None)
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS if ach else None, "avg_launch_us": ms / n * 1e3 if n else None, "launches_timed": n,
+            "algorithmic_bytes_per_launch": by / n if n else None, "traffic": traffic,
+            "traffic_source": (f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction 2*FETCH+WRITE)" if src else None)}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)                                          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: under an external launcher pass --gpus equal to the number of ranks")
     dist = None
-    local = local % max(1, torch.cuda.device_count())            # --backend gloo rehearsal: several ranks on one GPU
-    use_dist = world > 1 or a.force_dist
+    use_dist = world > 1 or a.force_dist or a.dry_run_collective
+    on_gpu = not a.dry_run_collective
+    if on_gpu:
+        local = local % max(1, torch.cuda.device_count())        # --backend gloo rehearsal: several ranks on one GPU
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -152,29 +272,60 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            torch.cuda.set_device(local)
-            if a.backend == "nccl":                               # RCCL over xGMI
+            if on_gpu:
+                torch.cuda.set_device(local)
+            if a.backend == "nccl" and on_gpu:                    # RCCL over xGMI
                 dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
             else:
                 dist.init_process_group("gloo")
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+
+    import aha_amd  # noqa: F401
+    from aha_amd.config import preset
+    from aha_amd.sharding import gather_scores
+    from aha_amd.synth import make_frames, make_token_ids, make_weights
+
+    B, F = a.streams, a.frames
+    n_streams_global = B * world                                  # stream g lives on rank g % world
+
+    def ranks_seen():
+        t = torch.tensor([rank], device=(f"cuda:{local}" if (on_gpu and a.backend == "nccl") else "cpu"))
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return len({int(x.item()) for x in out})
+
+    if a.dry_run_collective:
+        # launcher + rendezvous + collective plumbing on synthetic rows; nothing of the hot path runs and nothing is measured
+        loc = torch.full((F, B, 3), float(rank))
+        glob = gather_scores(loc, n_streams_global)
+        ok = glob.shape == (F, n_streams_global, 3) and all(float(glob[0, g, 0]) == g % world for g in range(n_streams_global))
+        seen = ranks_seen()
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "frames/sec scored (whole node)", "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
+                              "ranks_seen": seen, "gather_ok": bool(ok), "backend": "gloo", "steps": a.steps, "warmup": a.warmup}))
+        dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    from aha_amd.sharding import gather_scores
     from aha_amd.runtime import Runtime
 
     cfg = preset(a.preset)
     tf, H = cfg.frame_num_tokens, cfg.lm.hidden_size
-    B, F = a.streams, a.frames
     cache = None if a.cache == "none" else a.cache
     n_sys, n_query = 35, 20
+    secondary = (not a.no_secondary) and world == 1 and B == 1 and a.cache == "static" and a.preset == "bench"
+    B2 = 8                                                        # configs[3]: 64 streams over 8 GPUs
     w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=True)
-    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max(B * (tf + n_sys), 320), max_vit_frames=min(32, B * F),
+    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max((B2 if secondary else B) * (tf + n_sys), 320), max_vit_frames=32,
                  max_positions=cfg.lm.max_position_embeddings)
     if a.tile_dma >= 0:
         rt.set_tuning("tile_dma", a.tile_dma)
@@ -187,22 +338,9 @@ def main():
     query_ids = make_token_ids(n_query, cfg.lm.vocab_size, seed=101)
     frames = [make_frames(F, cfg.vision.image_size, seed=1000 * rank + s).to(dev) for s in range(B)]
     frames_all = torch.cat(frames, 0)                              # [B*F,3,S,S] stream-major
-    streams = [rt.open_stream(cache, a.window, a.sink, capacity=cfg.lm.max_position_embeddings) for _ in range(B)]
-    scores_host = torch.empty((F, B, 3), dtype=torch.float32).pin_memory()
-    scores_dev = torch.empty((F, B, 3), dtype=torch.float32, device=dev)
-    n_streams_global = B * world                                  # stream g lives on rank g % world
-
-    # stream prologue (untimed): query turn first (test/inference.py:294-298), then system prompt + frame 0
-    q = rt.embed_tokens(query_ids).view(1, -1, H).expand(B, -1, -1).contiguous()
-    rt.lm_step(streams, q)
-    emb0 = rt.visual_embed(frames_all[::F].contiguous()).view(B, tf, H)
-    pre = rt.embed_tokens(prefix_ids).view(1, -1, H).expand(B, -1, -1)
-    rt.lm_step(streams, torch.cat([pre, emb0], dim=1).contiguous())
 
     # The vision tower is MFMA-bound, the LM steps are HBM-bound and they use disjoint workspaces, so
-    # the tower of batch k+1 runs on a second HIP stream while the LM scores batch k (double-buffered
-    # embeddings, events both ways).  Every batch's encode and all of its LM steps are inside the
-    # timed region; --no-overlap serialises them on one stream.
+    # the tower of batch k+1 runs on a second HIP stream while the LM scores batch k.  --no-overlap serialises them.
     main_stream = torch.cuda.Stream(priority=-1) if a.lm_priority else torch.cuda.current_stream()   # LM chain: short kernels
     vit_stream = torch.cuda.Stream() if not a.no_overlap else main_stream
     if a.vit_cus > 0 and not a.no_overlap:
@@ -211,71 +349,52 @@ def main():
         if a.lm_cus != 0:
             lm_n = n_cu - a.vit_cus if a.lm_cus < 0 else a.lm_cus
             main_stream = cu_masked_stream(n_cu - lm_n, lm_n, n_cu)
-    emb_buf = [torch.empty((B * F * tf, H), dtype=torch.bfloat16, device=dev) for _ in range(2)]
-    emb_ready = [torch.cuda.Event() for _ in range(2)]
-    emb_free = [torch.cuda.Event() for _ in range(2)]
-    for e in emb_free:
-        e.record(main_stream)
 
-    def encode(k):
-        with torch.cuda.stream(vit_stream):
-            vit_stream.wait_event(emb_free[k & 1])                 # the LM is done with this slot
-            rt.visual_embed(frames_all, out=emb_buf[k & 1])
-            emb_ready[k & 1].record(vit_stream)
+    def gather(scores_dev):
+        loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
+        return gather_scores(loc, n_streams_global)               # -> [F, B*world, 3] in global stream order
 
-    def run(n_steps):
-        with torch.cuda.stream(main_stream):
-            _run(n_steps)
-
-    def _run(n_steps):
-        encode(0)
-        for k in range(n_steps):
-            if k + 1 < n_steps:
-                encode(k + 1)
-            main_stream.wait_event(emb_ready[k & 1])
-            emb = emb_buf[k & 1].view(B, F, tf, H)
-            for i in range(F):
-                scores_dev[i] = rt.lm_step(streams, emb[:, i].contiguous())
-            emb_free[k & 1].record(main_stream)
-            if use_dist:
-                # one collective per step on [F, B, 3] score rows -> [F, B*world, 3] in global stream order
-                loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
-                run.last_global = gather_scores(loc, n_streams_global)
-            scores_host.copy_(scores_dev, non_blocking=True)
+    wl = Workload(rt, cfg, dev, B, F, cache, a.window, a.sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream,
+                  gather if use_dist else None)
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(a.warmup)
+    wl.run(a.warmup)
     sync()
     t0 = time.perf_counter()
-    run(a.steps)
+    wl.run(a.steps)
     sync()
     dt = time.perf_counter() - t0
+    dist_info = None
     if use_dist:
         t = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert run.last_global.shape == (F, n_streams_global, 3) and torch.isfinite(run.last_global).all()
+        assert wl.last_global.shape == (F, n_streams_global, 3) and torch.isfinite(wl.last_global).all()
         dt = t.item()
-    assert torch.isfinite(scores_host).all()
-
-    # Dominant kernel: the gate/up weight-streaming GEMM (fused SwiGLU).  In the timed region the LM steps are replayed from
-    # a HIP graph and share the GPU with the next batch's vision tower, so the kernel is timed with HIP events (on its launch
-    # stream, around each of its 28 launches) on identical LM steps issued right after the region, with nothing else in
-    # flight: same process, same buffers, same stream state.  Average over 4 steps (112 launches).
-    emb_last = emb_buf[(a.steps - 1) & 1].view(B, F, tf, H)
-    rt.set_tuning("time_gemm", 1 << 2)
-    g_ms = g_bytes = 0.0
-    g_n = 0
-    for i in range(6):
-        rt.lm_step(streams, emb_last[:, i % F].contiguous())
+        # the collective on its own: one all-gather of the [F, B, 3] rows per step (latency-bound: a few hundred bytes per rank)
+        for _ in range(5):
+            gather(wl.scores_dev)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            gather(wl.scores_dev)
         torch.cuda.synchronize()
-        if i >= 2:                                                    # first two: direct launch, then graph capture
-            ms, n, by = rt.last_gemm_time(2)
-            g_ms, g_n, g_bytes = g_ms + ms, g_n + n, g_bytes + by
-    rt.set_tuning("time_gemm", 0)
+        ag_us = (time.perf_counter() - t1) / 50 * 1e6
+        dist_info = {"allgather_us": ag_us, "ranks_seen": ranks_seen(), "backend": "RCCL (torch.distributed nccl)" if a.backend == "nccl" else "gloo",
+                     "rows_per_rank": F * B, "bytes_per_rank": F * B * 12}
+        assert dist_info["ranks_seen"] == a.gpus
+        if a.backend == "nccl" and (a.abi_allgather or world == 1):
+            dist_info["c_abi_allgather"] = abi_allgather_check(dist, rt, wl.scores_dev, rank, world, local)
+    assert torch.isfinite(wl.scores_host).all()
+
+    # Dominant kernel: the gate/up weight-streaming GEMM (fused SwiGLU), timed with HIP events on its launch stream around each of
+    # its 28 launches per step, on identical LM steps issued right after the timed region with nothing else in flight: same
+    # process, same buffers, same stream state.  Timed steps are launched directly (not replayed), so the events are live.
+    emb_last = wl.last_emb(a.steps)
+    g_ms, g_n, g_bytes = timed_kind(rt, wl, emb_last, 2)
     wb, kvb, fl = rt.last_step_work()
 
     # p50 per-frame latency: ViT(1 frame) + LM step + score D2H, events on the launch stream
@@ -285,62 +404,17 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         e = rt.visual_embed(one).view(B, tf, H)
-        s = rt.lm_step(streams, e)
-        scores_host[0].copy_(s, non_blocking=True)
+        s = rt.lm_step(wl.streams, e)
+        wl.scores_host[0].copy_(s, non_blocking=True)
         e1.record()
         e1.synchronize()
         if i >= 8:
             lat.append(e0.elapsed_time(e1))
     lat.sort()
 
-    # secondary datum (NOT `value`): TrulyStaticCache frames are independent once the cache is frozen
-    # (test/static_cache.py:26-36; tests/test_gpu_parity.py proves it bit-exactly), so G frames of one stream can
-    # share one pass over the weights by listing the frozen stream G times in a single aha_lm_step.
-    static_batched = None
-    if a.cache == "static" and B == 1:
-        G = max(1, 320 // tf)                                          # rows one fused gate/up pass holds (gemm_ws: 20 row tiles)
-        def step_batched():
-            emb = rt.visual_embed(frames_all).view(F, tf, H)
-            for i in range(0, F, G):
-                g = min(G, F - i)
-                scores_dev[i:i + g, 0] = rt.lm_step(streams * g, emb[i:i + g].contiguous())
-            scores_host.copy_(scores_dev, non_blocking=True)
-        ref = scores_host.clone()
-        step_batched()
-        sync()
-        max_dev = (scores_host - ref).abs().max().item()             # vs the sequential pass on the same frames
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            step_batched()
-        sync()
-        dtb = time.perf_counter() - t1
-        static_batched = {"frames_per_lm_step": G, "frames_per_s": F * a.steps / dtb, "ms_per_step": dtb / a.steps * 1e3,
-                          "max_abs_score_diff_vs_sequential": max_dev}    # 0.0: bit-identical
-        # second observation (also NOT `value`): under the frozen static cache a new token attends only to the prefix,
-        # so the scores read at position -1 do not depend on the other tf-1 tokens of the frame; feeding only each
-        # frame's last token (at its RoPE position) is bit-identical and makes the step vision-bound.
-        def step_last_token():
-            emb = rt.visual_embed(frames_all).view(F, tf, H)
-            streams[0].set_position_offset(tf - 1)
-            for i in range(0, F, 16):                                 # at most 16 streams per aha_lm_step
-                g = min(16, F - i)
-                scores_dev[i:i + g, 0] = rt.lm_step(streams * g, emb[i:i + g, -1:].contiguous())
-            streams[0].set_position_offset(0)
-            scores_host.copy_(scores_dev, non_blocking=True)
-        step_last_token()
-        sync()
-        max_dev2 = (scores_host - ref).abs().max().item()
-        t2 = time.perf_counter()
-        for _ in range(a.steps):
-            step_last_token()
-        sync()
-        dtl = time.perf_counter() - t2
-        static_batched["last_token_only"] = {"frames_per_s": F * a.steps / dtl, "ms_per_step": dtl / a.steps * 1e3,
-                                             "max_abs_score_diff_vs_sequential": max_dev2}
-
     # per-kind GEMM breakdown of one LM step (diagnostic, outside the timed region)
     rt.set_tuning("time_gemm", 15)
-    rt.lm_step(streams, rt.visual_embed(one).view(B, tf, H))
+    rt.lm_step(wl.streams, rt.visual_embed(one).view(B, tf, H))
     torch.cuda.synchronize()
     kinds = {}
     for k, name in enumerate(["qkv", "o_proj", "gate_up_swiglu", "down_proj"]):
@@ -348,9 +422,18 @@ def main():
         kinds[name] = {"ms": round(ms, 4), "launches": n, "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
     rt.set_tuning("time_gemm", 0)
 
+    static_batched = sink_datum = eight_datum = None
+    if secondary:
+        static_batched = static_batching_datum(rt, wl, frames_all, F, tf, H, a.steps, sync)
+        wl.close()
+        sink_datum = sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_stream, vit_stream, sync)
+        eight_datum = eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync)
+    else:
+        wl.close()
+
     if rank == 0:
         total_frames = F * B * world * a.steps
-        achieved = (g_bytes / g_n) / ((g_ms / g_n) * 1e-3) / 1e9 if g_n else None
+        rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,")
         out = {
             "metric": "frames/sec scored (whole node)", "value": total_frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -361,15 +444,11 @@ def main():
                        "frames_per_step": F * B * world, "streams_per_gpu": B, "cache": a.cache, "vit_lm_overlap": not a.no_overlap,
                        "parallelism": f"stream-sharded x{world}" + (f", {'RCCL' if a.backend == 'nccl' else 'gloo'} all-gather of scores" if world > 1 else "")},
             "p50_frame_latency_ms": lat[len(lat) // 2],
-            "roofline": {"bound": "hbm", "kernel": "gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                         "avg_launch_us": g_ms / g_n * 1e3 if g_n else None, "launches_timed": g_n,
-                         "algorithmic_bytes_per_launch": g_bytes / g_n if g_n else None,
-                         "traffic": pmc_traffic("gemm_ws_kernel<3, 2,"),
-                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command, gfx950 correction 2*FETCH+WRITE); null when absent"},
+            "roofline": rf,
+            "distributed": dist_info,
             "static_cache_batched_frames": static_batched,
+            "sink_w2048": sink_datum,
+            "eight_stream_sink": eight_datum,
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
         }
         if want_cpu:
@@ -378,11 +457,152 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    for s in streams:
-        s.close()
     rt.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
+    """aha_allgather_scores (RCCL communicator built from a unique id inside libaha_amd.so) against torch.distributed's result."""
+    import ctypes as C
+    from aha_amd import lib as L
+    lib = L.get()
+    try:
+        idb = (C.c_ubyte * L.COMM_ID_BYTES)()
+        box = [None]
+        if rank == 0 and lib.aha_comm_unique_id(idb, L.COMM_ID_BYTES) == 0:
+            box[0] = bytes(idb)
+        dist.broadcast_object_list(box, src=0)                    # every rank learns whether rank 0 has an id: all init or none does
+        if box[0] is None:
+            return {"ok": False, "error": "aha_comm_unique_id failed: " + lib.aha_comm_last_error().decode()}
+        idb = (C.c_ubyte * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        rc = lib.aha_comm_init_rank(idb, L.COMM_ID_BYTES, world, rank, local, C.byref(comm))
+        if rc != 0:
+            return {"ok": False, "error": lib.aha_comm_last_error().decode()}
+        rows = scores_dev.shape[0] * scores_dev.shape[1]
+        loc = scores_dev.contiguous().view(rows, 3)
+        glob = torch.empty((world, rows, 3), dtype=torch.float32, device=scores_dev.device)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            lib.aha_allgather_scores(comm, loc.data_ptr(), rows, glob.data_ptr(), st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            rc = lib.aha_allgather_scores(comm, loc.data_ptr(), rows, glob.data_ptr(), st)
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / 50 * 1e6
+        want = [torch.empty_like(loc) for _ in range(world)]
+        dist.all_gather(want, loc)
+        ok = rc == 0 and torch.equal(glob, torch.stack(want))
+        lib.aha_comm_destroy(comm)
+        return {"ok": bool(ok), "allgather_us": us, "ranks": world}
+    except Exception as e:                                       # a diagnostic must not take the measurement down
+        return {"ok": False, "error": repr(e)}
+
+
+def static_batching_datum(rt, wl, frames_all, F, tf, H, steps, sync):
+    """secondary (NOT `value`): TrulyStaticCache frames are independent once the cache is frozen (test/static_cache.py:26-36;
+    tests/test_gpu_parity.py proves it bit-exactly), so G frames of one stream can share one pass over the weights by listing
+    the frozen stream G times in a single aha_lm_step; and only each frame's last token can influence its scores."""
+    G = max(1, 320 // tf)                                          # rows one fused gate/up pass holds (gemm_ws: 20 row tiles)
+    streams, scores_dev, scores_host = wl.streams, wl.scores_dev, wl.scores_host
+
+    def step_batched():
+        emb = rt.visual_embed(frames_all).view(F, tf, H)
+        for i in range(0, F, G):
+            g = min(G, F - i)
+            scores_dev[i:i + g, 0] = rt.lm_step(streams * g, emb[i:i + g].contiguous())
+        scores_host.copy_(scores_dev, non_blocking=True)
+    ref = scores_host.clone()
+    step_batched()
+    sync()
+    max_dev = (scores_host - ref).abs().max().item()             # vs the sequential pass on the same frames
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step_batched()
+    sync()
+    dtb = time.perf_counter() - t1
+    out = {"frames_per_lm_step": G, "frames_per_s": F * steps / dtb, "ms_per_step": dtb / steps * 1e3,
+           "max_abs_score_diff_vs_sequential": max_dev}            # 0.0: bit-identical
+
+    def step_last_token():
+        emb = rt.visual_embed(frames_all).view(F, tf, H)
+        streams[0].set_position_offset(tf - 1)
+        for i in range(0, F, 16):                                 # at most 16 streams per aha_lm_step
+            g = min(16, F - i)
+            scores_dev[i:i + g, 0] = rt.lm_step(streams * g, emb[i:i + g, -1:].contiguous())
+        streams[0].set_position_offset(0)
+        scores_host.copy_(scores_dev, non_blocking=True)
+    step_last_token()
+    sync()
+    max_dev2 = (scores_host - ref).abs().max().item()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        step_last_token()
+    sync()
+    dtl = time.perf_counter() - t2
+    out["last_token_only"] = {"frames_per_s": F * steps / dtl, "ms_per_step": dtl / steps * 1e3, "max_abs_score_diff_vs_sequential": max_dev2}
+    return out
+
+
+def sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_stream, vit_stream, sync):
+    """secondary: the same single-stream step on SinkCache(W=2048, sink=32) at STEADY STATE - cache full, every step evicts,
+    re-rotates the 1,980 kept keys of all 28 layers in place and attends over 2,048 keys (BASELINE configs[2] geometry)."""
+    F, tf = a.frames, cfg.frame_num_tokens
+    wl = Workload(rt, cfg, dev, 1, F, "default_sink", 2048, 32, frames_all[:F], prefix_ids, query_ids, main_stream, vit_stream)
+    fill = -(-(2048 // tf + 2) // F)                              # steps until the window is full
+    wl.run(fill)
+    sync()
+    assert wl.streams[0].get_seq_length() == 2048
+    steps = 5
+    t0 = time.perf_counter()
+    wl.run(steps)
+    sync()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(wl.scores_host).all()
+    emb = wl.last_emb(steps)
+    a_ms, a_n, a_by = timed_kind(rt, wl, emb, 4)
+    r_ms, r_n, r_by = timed_kind(rt, wl, emb, 5)
+    out = {"workload": f"1 stream, SinkCache W=2048 sink=32 at steady state (evicting every step), {F} frames/step",
+           "frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "roofline_attention": roofline_hbm("attn_fwd_kernel<128,true> + attn_combine_kernel (one layer: 2,048 keys x 4 KV heads, K and V read once)",
+                                              a_ms, a_n, a_by, "attn_fwd_kernel<128, true>"),
+           "roofline_rerotation": roofline_hbm("sink_rerotate_kernel<128> (all 28 layers: kept keys read + written in place)", r_ms, r_n, r_by,
+                                               "sink_rerotate_kernel")}
+    wl.close()
+    return out
+
+
+def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync):
+    """secondary: the per-GPU share of BASELINE configs[3] (64 streams over 8 GPUs): 8 streams batched into every LM step
+    (M = 288 rows per weight pass) on SinkCache(W=2048, sink=32) at steady state, vision encode of 8 x F frames per step."""
+    from aha_amd.synth import make_frames
+    F, tf = a.frames, cfg.frame_num_tokens
+    frames8 = torch.cat([make_frames(F, cfg.vision.image_size, seed=2000 + s).to(dev) for s in range(B2)], 0)
+    wl = Workload(rt, cfg, dev, B2, F, "default_sink", 2048, 32, frames8, prefix_ids, query_ids, main_stream, vit_stream)
+    fill = -(-(2048 // tf + 2) // F)
+    wl.run(fill)
+    sync()
+    assert all(s.get_seq_length() == 2048 for s in wl.streams)
+    steps = 3
+    t0 = time.perf_counter()
+    wl.run(steps)
+    sync()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(wl.scores_host).all()
+    emb = wl.last_emb(steps)
+    g_ms, g_n, g_by = timed_kind(rt, wl, emb, 2, n_steps=2)
+    M = B2 * tf
+    flops = 2.0 * M * (2 * cfg.lm.intermediate_size) * cfg.lm.hidden_size
+    tf_s = flops / ((g_ms / g_n) * 1e-3) / 1e12 if g_n else None
+    rl = roofline_hbm("gate/up GEMM + SwiGLU at M = 288 rows", g_ms, g_n, g_by)
+    rl.update({"mfma_achieved_TFLOPs": tf_s, "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS, "mfma_frac": tf_s / MFMA_PEAK_TFLOPS if tf_s else None,
+               "flops_per_launch": flops, "note": "arithmetic intensity ~288 flop/B sits on the ridge (312): both fractions are reported"})
+    out = {"workload": f"{B2} streams/GPU, SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step (M = {M} rows per LM step)",
+           "frames_per_s": B2 * F * steps / dt, "ms_per_step": dt / steps * 1e3, "roofline_gate_up": rl}
+    wl.close()
+    return out
 
 
 if __name__ == "__main__":

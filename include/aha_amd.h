@@ -252,10 +252,11 @@ const char* aha_comm_last_error(void);
 /* ---- introspection ------------------------------------------------------------------------- */
 /* algorithmic bytes / flops of the last aha_lm_step (SURVEY.md 8d accounting) */
 int aha_lm_last_step_work(aha_ctx* ctx, double* weight_bytes, double* kv_bytes, double* flops);
-/* time of the weight-streaming GEMM launches of the last step, measured with HIP events on the
- * launch stream when enabled with aha_ctx_set_tuning("time_gemm", mask) (bit k = kind k).  kind: 0 qkv, 1 o_proj,
- * 2 gate/up(+SwiGLU), 3 down_proj, 4 all.  Returns summed ms, launch count and the packed weight
- * bytes those launches streamed.  Synchronises on the recorded events. */
+/* time of one kind of launch of the last step, measured with HIP events on the launch stream when enabled with
+ * aha_ctx_set_tuning("time_gemm", mask) (bit k = kind k).  kind: 0 qkv, 1 o_proj, 2 gate/up(+SwiGLU), 3 down_proj
+ * (weight-streaming GEMMs; -1 = those four together), 4 attention over the KV cache (+ split combine), 5 SinkCache
+ * re-rotation.  Returns summed ms, launch-group count and the ALGORITHMIC bytes of those launches (packed weight bytes
+ * streamed; K+V bytes read; kept keys read + written).  Synchronises on the recorded events. */
 int aha_lm_last_gemm_time(aha_ctx* ctx, int kind, float* ms, int* launches, double* gemm_weight_bytes);
 const char* aha_version(void);
 

@@ -451,3 +451,29 @@ def test_checkpoint_with_lora_adapter_loads_into_the_runtime(tmp_path):
         dev = max(dev, (_rel(got1[i:i + 1]) - s32).abs().max().item())
         band = max(band, (sb - s32).abs().max().item())
     assert dev <= max(SCORE_TOL, 2.0 * band), (dev, band)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-GPU plumbing that a 1-GPU box can exercise
+# ---------------------------------------------------------------------------------------------------------------------
+def test_bench_launches_ranks_itself_and_the_rccl_path_runs():
+    """(1) `bench.py --gpus 2 --backend gloo` on ONE GPU: the launcher starts two ranks that share the card, each scores its
+    own streams, the score rows are all-gathered (gloo): n_gpus = 2, ranks_seen = 2, value counts both ranks' frames.
+    (2) one rank with --force-dist on the RCCL backend: barrier / all-gather / all-reduce through RCCL, and the C-ABI
+    collective (aha_comm_* + aha_allgather_scores) returns the same rows as torch.distributed."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    common = ["--preset", "tiny", "--steps", "2", "--warmup", "1", "--frames", "4", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"] + common,
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert out["n_gpus"] == 2 and out["distributed"]["ranks_seen"] == 2 and out["value"] > 0
+    assert out["config"]["frames_per_step"] == 8 and out["distributed"]["allgather_us"] > 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist"] + common, capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    d = out["distributed"]
+    assert out["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["backend"].startswith("RCCL")
+    assert d["c_abi_allgather"]["ok"] is True, d

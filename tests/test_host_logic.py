@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import aha_amd  # noqa: F401
+from conftest import ROOT
 from aha_amd.arguments import LiveTestArguments
 from aha_amd.config import preset
 from aha_amd.live_infer import (LiveInferForBenchmark, LiveInferForDemo, frames_to_canvases, round_numbers,
@@ -160,3 +161,24 @@ def test_stream_sharding_allgather_gloo(n_streams):
     want = np.stack([np.stack([[s + 0.1 * f, s + 0.2, -float(s)] for s in range(n_streams)]) for f in range(4)]).astype(np.float32)
     for r in (0, 1):
         np.testing.assert_allclose(ret[r], want)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE in the environment starts two ranks itself and relays rank 0's one JSON line
+    (dry run: launcher + rendezvous + gloo all-gather plumbing on synthetic score rows; nothing of the hot path runs on CPU)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run-collective",
+                        "--frames", "3", "--streams", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["gather_ok"] is True and out["dry_run"] is True and out["value"] is None
+    # under an external launcher a mismatching --gpus is refused loudly instead of mislabelling the run
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run-collective"], capture_output=True, text=True,
+                        timeout=120, env=env2)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
