@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary data (sink_w2048, eight_stream_sink, static batching)")
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
     p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
-    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
     p.add_argument("--abi-allgather", action="store_true",
@@ -452,7 +452,7 @@ def main():
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
         }
         if want_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, w_cpu, frames[0][:8].cpu(), prefix_ids, query_ids, a.cache, a.window,
+            out["cpu_baseline"] = cpu_baseline(cfg, w_cpu, frames[0][:32].cpu(), prefix_ids, query_ids, a.cache, a.window,
                                                a.sink, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None

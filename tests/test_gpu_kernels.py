@@ -8,7 +8,7 @@ random network:
   SwiGLU epilogue: given the SAME bf16 gate / up outputs (bit-identical k-order), <= 1 ulp, and >= 99.9 % bit-equal
   norms: h update bit-exact; normalised rows <= 1 ulp
   attention over the KV cache (ring addressing, sink wrap, key splits, causal edge): <= 1 ulp + the P->bf16 rounding bound
-      2^-9 * sum_j p_j |v_jd| that any flash/sdpa evaluation with bf16 probabilities carries; rows that put all their weight
+      2^-8 * sum_j p_j |v_jd| (unit roundoff of an 8-bit significand) that any flash/sdpa evaluation with bf16 probabilities carries; rows that put all their weight
       on ONE key at a boundary (first / last / sink edge / ring wrap / split edge / causal edge) must return that key's V.
   heads: raw logits <= 1 ulp; scores are exact functions of the raw logits.
   cache policies: ring contents after aha_cache_update == the reference's own SinkCache / SlidingWindowCache /
@@ -273,7 +273,7 @@ def test_attention_over_the_cache_flat_bound(op_rt, case):
     exact, pav = _attention_exact(q.view(T, d.heads, D), K, V, min(off, 1 << 20), scale)
     for split_len in (64, 256, 2048):
         got = rt.attention([st], q.view(1, T, -1), 0, causal_off=[off], split_len=split_len)[0]
-        e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -9 + 1e-4) * pav)
+        e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pav)
         _note(f"attention {case} split_len={split_len} Lk={Lk}", e)
         assert e.max().item() <= 1.0 + 1e-6, (case, split_len, e.max().item())
     st.close()
@@ -296,7 +296,7 @@ def test_attention_two_streams_of_different_length(op_rt):
         qs.append(q.view(T, -1)); exacts.append(ex); pavs.append(pav)
     got = rt.attention([a, b], torch.stack(qs), 0)
     for i in range(2):
-        e = ulp_error(got[i], exacts[i], floor=2.0 ** -10, slack=(2.0 ** -9 + 1e-4) * pavs[i])
+        e = ulp_error(got[i], exacts[i], floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pavs[i])
         assert e.max().item() <= 1.0 + 1e-6, (i, e.max().item())
     a.close(); b.close()
 
