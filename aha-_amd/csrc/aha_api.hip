@@ -96,6 +96,7 @@ struct aha_ctx {
     int wpb[GK_GEMMS] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
+    int use_wl = 1;                                         // tuning: mid-M GEMM kernel (gemm_wl.hip) for row chunks above 128 (0: gemm_ws everywhere)
     int layer_first = 0, layer_count = 0;                   // tuning: run only decoder layers [first, first+count) (0 = all); parity taps
     // generation scratch (aha_generate_greedy): next-token id, embedding row, penalty temporaries, device history count, host poll slot
     long* gen_tok = nullptr; bf16* gen_emb = nullptr; float* gen_tmp = nullptr; int* gen_nhist = nullptr; long* gen_out = nullptr;
@@ -287,6 +288,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "wpb_down") c->wpb[GK_DOWN] = value;
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
+    else if (k == "use_wl") c->use_wl = value;
     else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
     else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;
@@ -890,6 +892,18 @@ static GemmWsArgs ws_args(const bf16* X, int ldx, int M, int m0, int mrows, cons
     return a;
 }
 
+// Row chunking and kernel choice of the weight-streaming GEMMs.  M <= 128: gemm_ws (weights in registers).  Above that the
+// mid-M kernel (gemm_wl.hip: both operands through LDS-DMA stages) takes chunks of up to 320 rows; both kernels sum every
+// output element's k-steps in the same order with the same split-K slices, so the choice never changes a bit.
+static int ws_row_chunk(const aha_ctx* c, int epi, int M, int K) {
+    const bool wl_ok = c->use_wl && M > 128 && (epi == EPI_PARTIAL || epi == EPI_SWIGLU) && K % 32 == 0;
+    return wl_ok ? 320 : aha_gemm_ws_max_m(epi);
+}
+static hipError_t ws_or_wl(const aha_ctx* c, const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
+    if (c->use_wl && aha_gemm_wl_supports(a, epi)) return aha_gemm_wl(a, epi, st);
+    return aha_gemm_ws(a, epi, wpb, st);
+}
+
 // HIP-event bracket of one timed launch group (tuning "time_gemm": bit k = kind k), on the launch stream
 static int timed_begin(aha_ctx* c, int kind, hipStream_t st) {
     if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
@@ -910,12 +924,12 @@ static int timed_end(aha_ctx* c, int kind, double bytes, hipStream_t st) {
 
 static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
                    bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
-    const int mmax = aha_gemm_ws_max_m(epi);
+    const int mmax = ws_row_chunk(c, epi, M, w.K);
     const bool timed = kind >= 0 && ((c->time_gemm >> kind) & 1);      // time_gemm: bit k = GEMM kind k
     if (timed) { if (int rc = timed_begin(c, kind, st)) return rc; }
     for (int m0 = 0; m0 < M; m0 += mmax) {
         GemmWsArgs a = ws_args(X, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, w, S, partial, ldp, out, ldo, outf, ldof);
-        HIPCHK(c, aha_gemm_ws(&a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
+        HIPCHK(c, ws_or_wl(c, &a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
     }
     if (timed) { if (int rc = timed_end(c, kind, w.bytes() * ceil_div(M, mmax), st)) return rc; }
     c->last_weight_bytes += w.bytes();
@@ -1320,13 +1334,13 @@ extern "C" int aha_linear_forward(aha_ctx* c, const aha_linear* L, const void* x
     if (bias && epilogue != EPI_BF16) return fail(c, AHA_E_INVAL, "bias is supported by the bf16 epilogue only");
     hipStream_t st = (hipStream_t)st_;
     const int S = epilogue == EPI_PARTIAL ? aha_linear_split_k(c, L, split_k) : 1;
-    const int mmax = aha_gemm_ws_max_m(epilogue);
+    const int mmax = ws_row_chunk(c, epilogue, M, L->w.K);
     for (int m0 = 0; m0 < M; m0 += mmax) {
         GemmWsArgs a = ws_args((const bf16*)x, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, L->w, S, epilogue == EPI_PARTIAL ? (float*)out : nullptr,
                                ldo, epilogue == EPI_BF16 || epilogue == EPI_SWIGLU ? (bf16*)out : nullptr, ldo,
                                epilogue == EPI_F32_RBF ? (float*)out : nullptr, ldo);
         a.bias = (const bf16*)bias;
-        HIPCHK(c, aha_gemm_ws(&a, epilogue, 4, st));
+        HIPCHK(c, ws_or_wl(c, &a, epilogue, 4, st));
     }
     return 0;
 }

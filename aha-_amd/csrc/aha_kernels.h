@@ -87,6 +87,8 @@ struct QkvFinishArgs {
 extern "C" {
 int aha_gemm_ws_max_m(int epi);
 hipError_t aha_gemm_ws(const GemmWsArgs* a, int epi, int wpb, hipStream_t st);
+int aha_gemm_wl_supports(const GemmWsArgs* a, int epi);
+hipError_t aha_gemm_wl(const GemmWsArgs* a, int epi, hipStream_t st);
 hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, int tile_stride, int tile_off, hipStream_t st);
 hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);

@@ -111,6 +111,37 @@ def test_gemm_ws_every_epilogue_within_one_ulp(op_rt, M):
         h.close()
 
 
+@pytest.mark.parametrize("M", [129, 160, 200, 288, 320, 568])
+def test_mid_m_gemm_kernel_is_bit_identical_to_the_register_streaming_kernel(op_rt, M):
+    """Row blocks above 128 run gemm_wl.hip (both operands staged through LDS by LDS-DMA, five stages); it sums each output
+    element's k-steps in the same order with the same split-K slices as gemm_ws.hip, so switching it off (tuning use_wl = 0)
+    must not change one bit - for the split-K slabs and for the fused SwiGLU epilogue, ragged row counts included."""
+    cfg, _, rt = op_rt
+    g = _gen(300 + M)
+    try:
+        for N, K, S in ((4608, 3584, 7), (3584, 18944, 8), (3584, 3584, 8)):
+            x = (torch.randn(M, K, generator=g, device="cuda") * 0.5).bfloat16()
+            lin = rt.linear((torch.randn(N, K, generator=g, device="cuda") * 0.02).bfloat16())
+            out = {}
+            for use in (1, 0):
+                rt.set_tuning("use_wl", use)
+                out[use] = lin(x, L.EPI_SPLITK_F32, split_k=S).clone()
+            assert torch.equal(out[0], out[1]) and torch.isfinite(out[1]).all(), (M, N, K)
+            lin.close()
+        N, K = cfg.lm.intermediate_size, cfg.lm.hidden_size
+        x = (torch.randn(M, K, generator=g, device="cuda") * 0.5).bfloat16()
+        pair = rt.linear((torch.randn(N, K, generator=g, device="cuda") * 0.02).bfloat16(),
+                         (torch.randn(N, K, generator=g, device="cuda") * 0.02).bfloat16())
+        out = {}
+        for use in (1, 0):
+            rt.set_tuning("use_wl", use)
+            out[use] = pair(x, L.EPI_SWIGLU).clone()
+        assert torch.equal(out[0], out[1]) and torch.isfinite(out[1].float()).all(), M
+        pair.close()
+    finally:
+        rt.set_tuning("use_wl", 1)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # tiled MFMA GEMM (gemm_tile): the vision tower's and the projector's Linears
 # ---------------------------------------------------------------------------------------------------------------------
