@@ -33,7 +33,7 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
     constexpr int NB = MT + NTB;                                    // 1-KiB blocks per stage: MT of X, then NTB of W
     constexpr int PX = (MT + NW - 1) / NW, P = PX + 1;              // DMA wave-instructions per wave per stage: PX X blocks + its one W block
     constexpr int STAGE = NB * 512;                                 // bf16 elements per stage
-    static_assert(MT % 2 == 0 && (STAGES - 2) * P <= 63, "geometry");
+    static_assert(MT % 2 == 0 && STAGES >= 4 && (STAGES - 2) * P <= 63, "geometry");
     static_assert(EPI == EPI_PARTIAL || EPI == EPI_SWIGLU, "mid-M kernel: split-K slabs or fused SwiGLU");
     extern __shared__ __attribute__((aligned(16))) char wl_smem[];
     bf16* lds = reinterpret_cast<bf16*>(wl_smem);
@@ -78,24 +78,18 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
 #pragma unroll
     for (int i = 0; i < MH; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
     const int xslot = (r16 * 4 + (q ^ ((4 - (r16 >> 2)) & 3))) * 8;   // element offset of this lane's B fragment inside an X block
-    auto compute = [&](int stage) {
-        // every fragment of the k-step is requested before the first MFMA (11 ds_read_b128 in flight, ~44 VGPRs), so the LDS
-        // latency is paid once per k-step and the MFMAs then issue back to back; hipcc otherwise reads two fragments, waits,
-        // and issues four MFMAs at a time
-        const bf16* sa = lds + stage * STAGE;
-        const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(sa + (MT + wn * 2) * 512 + lane * 8);
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(sa + (MT + wn * 2 + 1) * 512 + lane * 8);
-        bf16x8 xf[MH];
-#pragma unroll
-        for (int i = 0; i < MH; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * MH + i) * 512 + xslot);
-        __builtin_amdgcn_sched_barrier(0);                          // keep the reads ahead of the MFMAs (counted lgkmcnt waits follow)
-#pragma unroll
-        for (int i = 0; i < MH; ++i) {
-            acc[i][0] = mfma16(w0, xf[i], acc[i][0]);
-            acc[i][1] = mfma16(w1, xf[i], acc[i][1]);
-        }
+    const int xoff = wm * MH * 512 + xslot, woff = (MT + wn * 2) * 512 + lane * 8;
+    bf16x8 xf[MH], w0, w1;
+    auto read_w = [&](int stage, bf16x8& a0, bf16x8& a1) {
+        const bf16* sa = lds + stage * STAGE + woff;
+        a0 = *reinterpret_cast<const bf16x8*>(sa);
+        a1 = *reinterpret_cast<const bf16x8*>(sa + 512);
     };
-
+    // One k-step: wait (this wave's blocks of k-step kt landed) -> barrier -> DMA k-step kt+STAGES-1 into the stage read last
+    // k-step -> all 11 fragment reads -> 18 MFMAs.  Two other schedules were A/B-ed on MI355X and tie within noise
+    // (profiles/r02_gemm_wl_ablation.txt): fragment reads software-pipelined one k-step ahead in place, and the DMA pieces
+    // spread between the MFMAs.  The ablations there show why: the MFMAs alone take 60 of the 92 us (10 waves sit 3/3/2/2
+    // on the 4 SIMDs and the chip holds ~1.6 GHz under the load); barrier, reads and DMA add 10 + 15 + 15.
     if (nk > 0) {
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) dma(s, s);
@@ -104,7 +98,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");   // this wave's blocks of k-step kt have landed
             __builtin_amdgcn_s_barrier();                            // everyone's have; everyone is done reading the stage refilled next
             dma(kt + STAGES - 1, st_new);
-            compute(st_cur);
+            read_w(st_cur, w0, w1);
+#pragma unroll
+            for (int i = 0; i < MH; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(lds + st_cur * STAGE + xoff + i * 512);
+            __builtin_amdgcn_sched_barrier(0);                      // keep the reads ahead of the MFMAs (hipcc otherwise reads 2, waits, issues 4)
+#pragma unroll
+            for (int i = 0; i < MH; ++i) {
+                acc[i][0] = mfma16(w0, xf[i], acc[i][0]);
+                acc[i][1] = mfma16(w1, xf[i], acc[i][1]);
+            }
             st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
             st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
         }
