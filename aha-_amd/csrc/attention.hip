@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDes
     f32x4 o[C::DT];
 #pragma unroll
     for (int i = 0; i < C::DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                         // m_run lives in the base-2 domain: c2 * max(score)
+    const float c2 = a.scale * 1.4426950408889634f;              // scale * log2(e)
 
     // K/V staging is issue-early / write-late with TWO key blocks in flight: register sets A and B hold blocks
     // jb+64 and jb+128 while block jb computes, so a workgroup's chain of key blocks (9 for one ViT frame, where
@@ -189,33 +190,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDes
                 s[kt] = mfma16(kf, qf[ks], s[kt]);
             }
         }
-        // ---- mask, scale, block max
-        float bmax = -INFINITY;
+        // ---- mask, block max, probabilities: the base-2 online softmax of attn_lm_kernel, operation for operation, so that a
+        // row gets the same bits from either kernel (a step's kernel is chosen by its shape; batched, solo and last-token-only
+        // evaluations of a row must agree exactly)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = jb + kt * 16 + 4 * q4 + e;
-                const bool vis = (j < j1) && (j <= off + t);
-                const float x = vis ? s[kt][e] * a.scale : -INFINITY;
-                s[kt][e] = x;
-                bmax = fmaxf(bmax, x);
+                if (!((j < j1) && (j <= off + t))) s[kt][e] = -INFINITY;
             }
+        float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt) bmax = fmaxf(bmax, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
         bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
         bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-        const float m_new = fmaxf(m_run, bmax);
+        const float m_new = fmaxf(m_run, bmax * c2);             // -inf * c2 = -inf
         float alpha = 1.f, psum = 0.f;
         bf16x8 pb[2];
         if (m_new == -INFINITY) {                            // nothing visible yet for this row
             pb[0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
             pb[1] = pb[0];
         } else {
-            alpha = __expf(m_run - m_new);                   // m_run = -inf -> 0
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // m_run = -inf -> 0
+            const float nm = -m_new;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = __expf(s[kt][e] - m_new);  // masked -> exp(-inf) = 0
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
                     psum += p;
                     pb[kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
                 }
@@ -468,6 +471,253 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LM attention for frame-sized steps (more than 64 query rows per KV head: T = 36 tokens x 7 query heads = 252 rows).
+// attn_fwd_kernel gives every 64-row group its own workgroup, so each (stream, KV head, key split) is staged from HBM/L2 into
+// LDS four times, through registers, with one block of keys in flight per workgroup: at L_kv = 2,048 it measured 11.5 us
+// (1 stream) / 24.7 us (8 streams) per layer for 4.2 / 33.5 MB of K/V - latency- and re-staging-bound (round 2 trace).  Here one
+// 8-wave workgroup owns ALL row tiles of a (stream, KV head, key split) - two 16-row tiles per wave, up to 256 rows - so
+// K/V are staged once, by LDS-DMA (global_load_lds_dwordx4 straight from the ring slots: the per-lane SOURCE address carries
+// the ring mapping and the swizzles), three 64-key stages deep behind a counted vmcnt and one raw s_barrier per block, and
+// every K fragment / transposed V fragment read from LDS feeds two MFMAs.  LDS images (an LDS-DMA writes lane-linear, 4 key
+// rows of 256 B per wave-instruction):
+//   K: chunk c of key row r at slot  r*16 + (c ^ (r & 15))         -> conflict-free ds_read_b128 A fragments (as attn_fwd_kernel)
+//   V: chunk c of key row r at slot  r*16 + (c ^ (2 * (r & 7)))    -> conflict-free ds_read_b64_tr_b16: a 32-lane half reads
+//      8 rows x 4 eight-byte pieces of two adjacent chunks; rows are 64 banks apart, so the XOR of the chunk PAIR index with
+//      (r & 7) puts the 8 rows on 8 different bank octets.
+// Same visibility rule, online softmax and partial format as attn_fwd_kernel (attn_combine merges key splits).
+// ---------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_lm_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
+    static_assert(D == 128, "built for head_dim 128 (16 chunks per key row)");
+    static_assert(NW == 8 || NW == 4 || NW == 2, "waves per workgroup (8 is the shipped one; 4 and 2 were measured slower than attn_fwd_kernel)");
+    constexpr int STG = 64 * D;                  // elements of one operand of one stage (64 keys)
+    constexpr int PPW = 16 / NW;                 // K (and V) pieces per wave and stage (1 KiB = 4 key rows each; 16 per operand)
+    constexpr int STAGES = 3, P = 2 * PPW;
+    constexpr int DT = D / 16, KSQ = D / 32;
+    extern __shared__ __attribute__((aligned(16))) char alm_smem[];
+    bf16* lds = reinterpret_cast<bf16*>(alm_smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int b = blockIdx.z;
+    const int R = a.G * a.T, RT = ceil_div(R, 16), RGW = ceil_div(RT, 2 * NW);      // a workgroup covers 2*NW row tiles
+    const int hk = blockIdx.y / RGW, rg = blockIdx.y % RGW;
+    const int split = blockIdx.x;
+    const StreamStep ss = sdp->s[b];
+    const int Lk = ss.len_after, off = ss.causal_off;
+    const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
+    const bf16* kb = ss.k_base + lo;
+    const bf16* vb = ss.v_base + lo;
+    const int j0 = split * a.split_len;
+    const int j1 = min(Lk, j0 + a.split_len);
+    if (j0 >= j1) return;                                   // uniform per block
+    const int nblk = ceil_div(j1 - j0, 64);
+
+    // ---- this wave's two query tiles
+    int trow[2], thead[2];
+    bool row_ok[2];
+    bf16x8 qf[2][KSQ];
+    const int rt0 = (rg * NW + wave) * 2;
+    const bool wave_on = rt0 < RT;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        int r = (rt0 + tt) * 16 + r16;
+        row_ok[tt] = (rt0 + tt) < RT && r < R;
+        if (r > R - 1) r = R - 1;
+        const int g = r / a.T;
+        trow[tt] = r % a.T;
+        thead[tt] = hk * a.G + g;
+        const bf16* qp = a.q + b * a.q_bs + (long)trow[tt] * a.ldq + thead[tt] * D;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) qf[tt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + q4 * 8);
+    }
+
+    // ---- LDS-DMA of one 64-key block: piece (wave*2 + pk) = key rows 4*(wave*2+pk) .. +3 of the block, K and V
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int prow = lane >> 4, pch = lane & 15;
+    auto dma = [&](int blk, int stage) {
+        const int jb = j0 + min(blk, nblk - 1) * 64;        // past the end: refill a dead stage (keeps the vmcnt counts fixed)
+        bf16* sk = lds + stage * (2 * STG);
+#pragma unroll
+        for (int pk = 0; pk < PPW; ++pk) {
+            const int row = (wave * PPW + pk) * 4 + prow;
+            const int j = min(jb + row, j1 - 1);            // keys past the end re-load the last key: finite data, masked below
+            const long so = (long)phys_slot(ss, j) * D;
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + so + ((pch ^ (row & 15)) << 3)), (lptr_t)(sk + (wave * PPW + pk) * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + so + ((pch ^ (2 * (row & 7))) << 3)), (lptr_t)(sk + STG + (wave * PPW + pk) * 512), 16, 0, 0);
+        }
+    };
+
+    f32x4 o[2][DT];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        m_run[tt] = -INFINITY;
+        l_run[tt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[tt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int vrow = 4 * q4 + (r16 >> 2), vcol = 4 * (r16 & 3);
+    const float c2 = a.scale * 1.4426950408889634f;              // scale * log2(e)
+
+    auto compute = [&](int stage, int jb) {
+        const bf16* Ks = lds + stage * (2 * STG);
+        const bf16* Vs = Ks + STG;
+        // ---- S^T tiles of both query tiles: every K fragment feeds two MFMAs
+        f32x4 s[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int row = kt * 16 + r16;
+            bf16x8 kf[KSQ];
+#pragma unroll
+            for (int ks = 0; ks < KSQ; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (row & 15)) << 3)]);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                s[tt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSQ; ++ks) s[tt][kt] = mfma16(kf[ks], qf[tt][ks], s[tt][kt]);
+            }
+        }
+        // ---- online softmax in the base-2 domain (softmax(scale*s) = 2^(c2*s - c2*max), c2 = scale*log2(e) > 0): one FMA and one
+        // v_exp_f32 per probability.  The visibility mask costs ~5 VALU per score, so it is applied only in blocks that touch
+        // the causal edge or the end of the split (wave-uniform test); the accumulator rescale is skipped while no row's
+        // running maximum moved.  This kernel was VALU-bound on exactly these three (round-2 trace: 6.4k cycles per block).
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bool all_vis = __all((jb + 63 <= off + trow[tt]) && (jb + 64 <= j1));
+            if (!all_vis) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = jb + kt * 16 + 4 * q4 + e;
+                        if (!((j < j1) && (j <= off + trow[tt]))) s[tt][kt][e] = -INFINITY;
+                    }
+            }
+            float bmax = fmaxf(fmaxf(s[tt][0][0], s[tt][0][1]), fmaxf(s[tt][0][2], s[tt][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) bmax = fmaxf(bmax, fmaxf(fmaxf(s[tt][kt][0], s[tt][kt][1]), fmaxf(s[tt][kt][2], s[tt][kt][3])));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const float m_new = fmaxf(m_run[tt], bmax * c2);        // -inf * c2 = -inf
+            float alpha = 1.f, psum = 0.f;
+            if (m_new == -INFINITY) {                        // nothing visible yet for this row
+                pb[tt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                pb[tt][1] = pb[tt][0];
+            } else {
+                alpha = __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf -> 0
+                const float nm = -m_new;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[tt][kt][e], c2, nm));   // masked: 2^-inf = 0
+                        psum += p;
+                        pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                    }
+            }
+            m_run[tt] = m_new;
+            l_run[tt] = l_run[tt] * alpha + psum;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int i = 0; i < DT; ++i) o[tt][i] *= alpha;
+            }
+        }
+        // ---- O^T += V^T P^T: one transposed V fragment feeds both tiles (k-slot permutation as in attn_fwd_kernel)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int rlo = (2 * kp) * 16 + vrow, rhi = rlo + 16, col = dt * 16 + vcol;
+                const s16x4 vlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[rlo * D + ((((col >> 3) ^ (2 * (rlo & 7)))) << 3) + (col & 7)]));
+                const s16x4 vhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[rhi * D + ((((col >> 3) ^ (2 * (rhi & 7)))) << 3) + (col & 7)]));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vlo, vhi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) o[tt][dt] = mfma16(vf, pb[tt][kp], o[tt][dt]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st) dma(st, st);
+    int st_cur = 0, st_new = STAGES - 1;
+    for (int blk = 0; blk < nblk; ++blk) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");       // this wave's pieces of block blk have landed
+        __builtin_amdgcn_s_barrier();                        // everyone's have; everyone is done reading the stage refilled next
+        dma(blk + STAGES - 1, st_new);
+        if (wave_on) compute(st_cur, j0 + blk * 64);
+        st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
+        st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing may still target LDS when the workgroup retires
+    if (!wave_on) return;
+
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float l = l_run[tt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[tt]) continue;
+        if (a.n_splits == 1) {
+            const float inv = 1.0f / l;
+            bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * D + 4 * q4;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ov = {f2bf(o[tt][dt][0] * inv), f2bf(o[tt][dt][1] * inv), f2bf(o[tt][dt][2] * inv), f2bf(o[tt][dt][3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+            }
+        } else {
+            const int Rpad = RT * 16;
+            const long prw = (((long)b * a.Hkv + hk) * a.n_splits + split) * Rpad + ((rt0 + tt) * 16 + r16);
+            float* po = a.part_o + prw * D + 4 * q4;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16) = o[tt][dt];
+            if (q4 == 0) {
+                a.part_ml[prw * 2] = m_run[tt];
+                a.part_ml[prw * 2 + 1] = l;
+            }
+        }
+    }
+}
+
+// Merge key splits, 16 query rows per 256-thread block: a thread owns 8 output channels of one row (two 16-B partial loads per
+// split, one 16-B store), so the 8,064 tiny blocks of attn_combine_kernel at 8 streams become 512.  Same summation order over
+// the splits as attn_combine_kernel.
+template <int D>
+__global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
+    static_assert(D == 128, "16 threads x 8 channels per row");
+    const int R = a.G * a.T, RT = ceil_div(R, 16), Rpad = RT * 16;
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), d0 = (threadIdx.x & 15) * 8;
+    const int hk = blockIdx.y, b = blockIdx.z;
+    if (r >= R) return;
+    const int Lk = sdp->s[b].len_after;
+    const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
+    const long base = ((long)b * a.Hkv + hk) * a.n_splits;
+    float M = -INFINITY;
+    for (int s = 0; s < ns; ++s) M = fmaxf(M, a.part_ml[((base + s) * Rpad + r) * 2]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const long prow = (base + s) * Rpad + r;
+        const float w = __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // attn_lm_kernel keeps its running maxima in the base-2 domain
+        L += w * a.part_ml[prow * 2 + 1];
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0), p1 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += w * p0[e]; acc[4 + e] += w * p1[e]; }
+    }
+    const int g = r / a.T, t = r % a.T;
+    bf16x8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e] / L);
+    *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
+}
+
 // Merge key splits: one block of D threads per (b, kv head, row).
 template <int D>
 __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
@@ -481,7 +731,7 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
     float acc = 0.f, L = 0.f;
     for (int s = 0; s < ns; ++s) {
         const long prow = (base + s) * Rpad + r;
-        const float w = __expf(a.part_ml[prow * 2] - M);
+        const float w = __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima are kept in the base-2 domain
         L += w * a.part_ml[prow * 2 + 1];
         acc += w * a.part_o[prow * D + d];
     }
@@ -491,12 +741,34 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
 
 static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of the dense kernel (0 = auto, 1..3 forced)
 extern "C" void aha_attention_set_dense_tpw(int v) { g_dense_tpw = v; }
+static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-sized steps (> 64 rows per KV head, head_dim 128): 0 never, 1 auto, 2 always
+extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
 template <int D>
 static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, hipStream_t st) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
     dim3 grid(a.n_splits, a.Hkv * RG, B);
     if (sd_dev) {
+        if constexpr (D == 128) {
+            // attn_lm_kernel (all 16 row tiles of a frame-sized step share one K/V staging) once its grid fills half the chip
+            // (4+ streams at W = 2,048: measured 34.7 vs 49.8 us per layer at 8 streams); with fewer streams attn_fwd_kernel's
+            // four narrower workgroups per (stream, KV head, split) win (20.6 vs 22.7 us at one stream).  Both kernels give a
+            // row the same bits, so the choice - which depends on the batch - cannot change a score.
+            const int wgs8 = a.n_splits * a.Hkv * ceil_div(RT, 16) * B;
+            if (a.hd == D && RT > 4 && (g_attn_lm == 2 || (g_attn_lm == 1 && wgs8 >= 128))) {      // tuning "attn_lm": 0 never, 1 auto, 2 always
+                constexpr int LDS = 3 * 2 * 64 * D * 2;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    hipError_t e = hipFuncSetAttribute((const void*)attn_lm_kernel<D, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    if (e != hipSuccess) return e;
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((attn_lm_kernel<D, 8>), dim3(a.n_splits, a.Hkv * ceil_div(RT, 16), B), dim3(512), LDS, st, a, sd_dev);
+                if (a.n_splits > 1)
+                    hipLaunchKernelGGL((attn_combine16_kernel<D>), dim3(ceil_div(R, 16), a.Hkv, B), dim3(256), 0, st, a, sd_dev);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, st, a, sd_dev);
         if (a.n_splits > 1)
             hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, sd_dev);

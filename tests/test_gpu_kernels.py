@@ -310,6 +310,34 @@ def test_attention_over_the_cache_flat_bound(op_rt, case):
     st.close()
 
 
+@pytest.mark.parametrize("case", ["short_growing", "sink_wrapped_2048"])
+def test_both_lm_attention_kernels_give_a_row_the_same_bits(op_rt, case):
+    """A step's attention kernel is chosen by its shape (attn_lm_kernel: all row tiles of a frame-sized step in one 8-wave
+    workgroup, LDS-DMA staging, once that fills the chip; attn_fwd_kernel otherwise).  Batched, solo and last-token-only
+    evaluations of a row must agree exactly, so the two kernels must: forced both ways (tuning attn_lm = 0 / 2), every key-split
+    shape, and a single-token step (always attn_fwd_kernel) against the same row inside a frame-sized one."""
+    cfg, _, rt = op_rt
+    d = rt.desc
+    T, D = 36, d.head_dim
+    g = _gen(31)
+    st = rt.open_stream(None, capacity=4096) if case == "short_growing" else rt.open_stream("default_sink", 2048, 32)
+    _fill(rt, st, 20 + T if case == "short_growing" else 20 + 75 * T, g)
+    Lk = st.get_seq_length()
+    q = (torch.randn(1, T, d.heads * D, generator=g, device="cuda") * 2).bfloat16()
+    try:
+        for split_len in (64, 256, 2048):
+            out = {}
+            for mode in (0, 2):
+                rt.set_tuning("attn_lm", mode)
+                out[mode] = rt.attention([st], q, 0, causal_off=[Lk - T], split_len=split_len).clone()
+            assert torch.equal(out[0], out[2]) and torch.isfinite(out[0].float()).all(), (case, split_len)
+            last = rt.attention([st], q[:, -1:].contiguous(), 0, causal_off=[Lk - 1], split_len=split_len)   # the last row alone sees every key too
+            assert torch.equal(last[0, 0], out[2][0, -1]), (case, split_len)
+    finally:
+        rt.set_tuning("attn_lm", 1)
+    st.close()
+
+
 def test_attention_two_streams_of_different_length(op_rt):
     cfg, _, rt = op_rt
     d = rt.desc

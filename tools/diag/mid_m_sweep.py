@@ -50,17 +50,16 @@ def step_ms(sts, x, n=30):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for B in (1, 8):
+for B in (1, 2, 8):
     sts, x = fill(B)
-    for use_wl in ((1,) if B == 1 else (0, 1)):
+    for use_wl in (1,):
         rt.set_tuning("use_wl", use_wl)
         k = kinds(sts, x)
         print(f"B={B} use_wl={use_wl}: step {step_ms(sts, x):.3f} ms; us per launch group: " + "  ".join(f"{a} {b:.1f}" for a, b in k.items()), flush=True)
     rt.set_tuning("use_wl", 1)
-    for sl in (64, 128, 256, 512):
-        rt.set_tuning("attn_split_len", sl)
+    for nw in (0, 8, 4, 2, 1):
+        rt.set_tuning("attn_lm", nw)
         k = kinds(sts, x)
-        print(f"B={B} attn_split_len={sl}: step {step_ms(sts, x):.3f} ms; attn {k['attn']:.1f} us", flush=True)
-    rt.set_tuning("attn_split_len", 0)
+        print(f"B={B} attn_lm={nw}: step {step_ms(sts, x):.3f} ms; attn {k['attn']:.1f} us", flush=True)
     for s in sts:
         s.close()
