@@ -102,6 +102,7 @@ struct aha_ctx {
     long* gen_tok = nullptr; bf16* gen_emb = nullptr; float* gen_tmp = nullptr; int* gen_nhist = nullptr; long* gen_out = nullptr;
     long* gen_pin = nullptr; hipEvent_t gen_ev = nullptr; int gen_cap = 0;
     // operator-level attention (aha_attention_forward): its own descriptor slot ring is the step's (sd_pin / sd_dev)
+    int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
     // accounting of the last step
@@ -292,6 +293,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
     else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;
+    else if (k == "static_attn") c->static_attn = value;
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
@@ -1061,6 +1063,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     for (int b = 0; b < B; ++b) all_static_frozen = all_static_frozen && sd.s[b].write_base < 0;
     const bool q_only = all_static_frozen && c->fuse_static != 0;
     const bool frozen_all = all_static_frozen && c->fuse_static == 1;
+    // ... and with a short frozen prefix (configs[1]: the 20-token query turn) qkv_finish and the attention are one launch on the
+    // vector ALUs (elementwise.hip: qkv_finish_attn_static_kernel; tuning "static_attn", on by default)
+    const bool static_attn = all_static_frozen && !frozen_all && c->static_attn && max_lk <= 64 && G <= 8;
 
     // Everything from the first RMSNorm to the heads, on stream `st`, scores to `scores_out`: run directly, or recorded
     // into a HIP graph (below).
@@ -1084,6 +1089,21 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
             AttnArgs a;
             memset(&a, 0, sizeof(a));
+            if (static_attn) {
+                QkvFinishArgs qa;
+                memset(&qa, 0, sizeof(qa));
+                qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+                qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+                qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+                const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
+                if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
+                HIPCHK(c, aha_qkv_finish_attn_static(&qa, c->sd_dev, M, c->attn_out, QD, 1.0f / sqrtf((float)Dh), st));
+                if (t_attn) {
+                    double by = 0;
+                    for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;
+                    if ((rc = timed_end(c, GK_ATTN, by, st))) return rc;
+                }
+            } else {
             if (!frozen_all) {
                 QkvFinishArgs qa;
                 memset(&qa, 0, sizeof(qa));
@@ -1108,6 +1128,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 double by = 0;
                 for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;
                 if ((rc = timed_end(c, GK_ATTN, by, st))) return rc;
+            }
             }
             // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
             const int So = pick_split(c, GK_O, w.o, M, 1);
@@ -1166,7 +1187,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     // set kernel attribute has been set by then); any failure falls back to direct launches for that shape.  The descriptor
     // upload, the sink re-rotation and the input / score copies stay outside the graph.
     const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
-    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0);
+    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0);
     // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
     // does not become a graph node, so a replay would leave the events holding stale timestamps.)
     if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp && !c->time_gemm) {

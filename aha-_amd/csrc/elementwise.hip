@@ -146,6 +146,130 @@ __global__ __launch_bounds__(1024) void qkv_finish_kernel(QkvFinishArgs a, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Frozen TrulyStaticCache steps with a short prefix (BASELINE configs[1]: the 20-token query turn): qkv_finish AND the
+// attention in one launch.  After its first call the static cache returns only the frozen prefix (test/static_cache.py:33-36),
+// so a new token's attention needs its own rotated query rows and the <= 64 cached keys - nothing another workgroup
+// produces.  One workgroup per (token row, KV head): split-K reduce + bias + RoPE of the G query heads that share the KV head
+// (same rounding points as qkv_finish_kernel), then softmax(q K^T) V on the vector ALUs (G x L_kv x D = 18k MACs per
+// workgroup: far too small for a tile kernel, whose launch + LDS staging + MFMA drain cost 8.9 us here against 1-2 us).
+// The step's K/V projections are not consumed (nothing is stored for a frozen cache); every cached key is visible.
+// Arithmetic (this kernel's own; rows independent, so batched, solo and last-token-only steps agree bit for bit):
+//   s_j = sum_d q_d k_jd in d order (fp32);  p_j = 2^(c2 s_j - c2 max_j s_j), c2 = scale log2 e;  l = sum_j p_j (fp32);
+//   out_d = bf16( (sum_j bf16(p_j) v_jd in j order) / l )  - P rounded to bf16 before PV like the tile kernels.
+// ---------------------------------------------------------------------------------------------
+struct StaticAttnArgs {
+    QkvFinishArgs qa;
+    bf16* out; int ldo;              // attention output rows [M][Hq*D]
+    float scale; int G;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnArgs p, const StepDesc* __restrict__ sdp) {
+    constexpr int HALF = D / 2, IPH = HALF / 4, KST = D + 8, GMAX = 8, LMAX = 64;
+    __shared__ __attribute__((aligned(16))) bf16 Ksh[LMAX * KST];
+    __shared__ __attribute__((aligned(16))) bf16 Vsh[LMAX * KST];
+    __shared__ float qs[GMAX * D];
+    __shared__ float ps[GMAX * LMAX];
+    const QkvFinishArgs& a = p.qa;
+    const int row = blockIdx.x, hk = blockIdx.y, tid = threadIdx.x, G = p.G;
+    const int T = sdp->T, b = row / T, t = row % T;
+    const StreamStep ss = sdp->s[b];
+    const int Lk = min(ss.len_after, LMAX);
+    int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
+
+    // ---- the frozen prefix of this KV head -> LDS (issued first: independent of the slab reduce below)
+    {
+        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
+        for (int c = tid; c < Lk * (D / 8); c += 256) {
+            const int j = c / (D / 8), ch = c % (D / 8);
+            const long so = lo + (long)phys_slot(ss, j) * D + ch * 8;
+            *reinterpret_cast<bf16x8*>(&Ksh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.k_base + so);
+            *reinterpret_cast<bf16x8*>(&Vsh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.v_base + so);
+        }
+    }
+    // ---- rotated queries of the G heads (qkv_finish_kernel's arithmetic)
+    auto fetch4 = [&](int col, float (&o)[4]) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* pp = a.partial + (long)row * a.ldp + col;
+        for (int s0 = 0; s0 < a.S; s0 += 8) {
+            f32x4 tt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < a.S) tt[j] = *reinterpret_cast<const f32x4*>(pp + (s0 + j) * a.slab_stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < a.S) acc += tt[j];
+        }
+        const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rbf(acc[e] + bf2f(bv[e]));
+    };
+    for (int it = tid; it < G * IPH; it += 256) {
+        const int g = it / IPH, dd = (it % IPH) * 4, col = (hk * G + g) * D + dd;
+        float x1[4], x2[4];
+        fetch4(col, x1);
+        fetch4(col + HALF, x2);
+        const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + dd), s1 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + dd);
+        const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + dd + HALF), s2 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + dd + HALF);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qs[g * D + dd + e] = rbf(rbf(x1[e] * bf2f(c1[e])) + rbf(-x2[e] * bf2f(s1[e])));
+            qs[g * D + dd + HALF + e] = rbf(rbf(x2[e] * bf2f(c2[e])) + rbf(x1[e] * bf2f(s2[e])));
+        }
+    }
+    __syncthreads();
+    // ---- scores
+    for (int i = tid; i < G * Lk; i += 256) {
+        const int g = i / Lk, j = i % Lk;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int dch = 0; dch < D / 8; ++dch) {
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(&Ksh[j * KST + dch * 8]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = __builtin_fmaf(qs[g * D + dch * 8 + e], bf2f(kv[e]), acc);
+        }
+        ps[g * LMAX + j] = acc;
+    }
+    __syncthreads();
+    // ---- softmax numerators (every thread of a head recomputes the head's max: <= 64 LDS reads)
+    const float c2 = p.scale * 1.4426950408889634f;
+    float pj[2] = {0.f, 0.f};                                   // G * Lk <= 8 * 64 = 512 = two per thread
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        if (i < G * Lk) {
+            const int gi = i / Lk;
+            float m = -INFINITY;
+            for (int j = 0; j < Lk; ++j) m = fmaxf(m, ps[gi * LMAX + j]);
+            pj[u] = __builtin_amdgcn_exp2f(__builtin_fmaf(ps[gi * LMAX + i % Lk], c2, -m * c2));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        if (i < G * Lk) ps[(i / Lk) * LMAX + i % Lk] = pj[u];
+    }
+    __syncthreads();
+    // ---- out[g][d] = sum_j bf16(p_j) v_jd / sum_j p_j
+    for (int i = tid; i < G * (D / 4); i += 256) {
+        const int g = i / (D / 4), dd = (i % (D / 4)) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
+        for (int j = 0; j < Lk; ++j) {
+            const float pv = ps[g * LMAX + j];
+            l += pv;
+            const float pb = rbf(pv);
+            const bf16x4 vv = *reinterpret_cast<const bf16x4*>(&Vsh[j * KST + dd]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(pb, bf2f(vv[e]), acc[e]);
+        }
+        const float inv = 1.0f / l;
+        bf16x4 o = {f2bf(acc[0] * inv), f2bf(acc[1] * inv), f2bf(acc[2] * inv), f2bf(acc[3] * inv)};
+        *reinterpret_cast<bf16x4*>(p.out + (long)row * p.ldo + (hk * G + g) * D + dd) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SinkCache re-rotation of the kept window keys, in place (test/sink_cache.py:27-33,139-150):
 //   k' = bf16( bf16(k*cos_r) + bf16(rotate_half(k)*sin_r) ), table row = rerot_row0 + kept index.
 // In the ring layout kept keys do not move, so this is the ONLY per-step traffic on old keys.
@@ -503,6 +627,16 @@ hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M,
     if (groups > 16) groups = 16;
     if (a->D == 64) hipLaunchKernelGGL((qkv_finish_kernel<64>), dim3(M, groups), dim3(threads), 0, st, *a, sd_dev);
     else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_kernel<128>), dim3(M, groups), dim3(threads), 0, st, *a, sd_dev);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+// G <= 8 query heads per KV head, every stream's frozen prefix <= 64 keys (the caller checks both)
+hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, bf16* out, int ldo, float scale, hipStream_t st) {
+    StaticAttnArgs p;
+    p.qa = *a; p.out = out; p.ldo = ldo; p.scale = scale; p.G = a->Hq / a->Hkv;
+    if (p.G > 8) return hipErrorInvalidValue;
+    if (a->D == 64) hipLaunchKernelGGL((qkv_finish_attn_static_kernel<64>), dim3(M, a->Hkv), dim3(256), 0, st, p, sd_dev);
+    else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_attn_static_kernel<128>), dim3(M, a->Hkv), dim3(256), 0, st, p, sd_dev);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

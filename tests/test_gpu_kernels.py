@@ -338,6 +338,37 @@ def test_both_lm_attention_kernels_give_a_row_the_same_bits(op_rt, case):
     st.close()
 
 
+def test_fused_static_finish_and_attention_matches_the_tile_kernels(op_rt):
+    """Frozen TrulyStaticCache steps with a short prefix run qkv_finish + attention as ONE launch on the vector ALUs
+    (qkv_finish_attn_static_kernel).  Its attention output must sit within 2 bf16 ulps (at the tensor's scale) of the
+    qkv_finish -> attn_fwd_kernel pair on the same step (same rotated queries, same keys; only the summation order of the
+    128-deep dot products and of the <= 64-key PV sums differs), for 20- and 64-key prefixes, T = 36 and T = 1, two streams."""
+    cfg, _, rt = op_rt
+    H = cfg.lm.hidden_size
+    g = _gen(41)
+    try:
+        for n_prefix in (20, 64):
+            for T, B in ((36, 1), (1, 2), (36, 2)):
+                outs = {}
+                for mode in (0, 1):
+                    rt.set_tuning("static_attn", mode)
+                    gg = torch.Generator(device="cuda").manual_seed(1000 + n_prefix)
+                    sts = [rt.open_stream("static", 2048, 0) for _ in range(B)]
+                    rt.lm_step(sts, (torch.randn(B, n_prefix, H, generator=gg, device="cuda") * 0.5).bfloat16())
+                    x = (torch.randn(B, T, H, generator=gg, device="cuda") * 0.5).bfloat16()
+                    sc = rt.lm_step(sts, x).clone()
+                    outs[mode] = (rt.debug_tap("attn_out", B, T).clone(), sc)
+                    for s_ in sts:
+                        s_.close()
+                a0, a1 = outs[0][0].float(), outs[1][0].float()
+                e = ulp_error(a1, a0.double(), floor=rms(a0))
+                _note(f"fused static attention prefix={n_prefix} T={T} B={B}", e)
+                assert e.max().item() <= 2.0, (n_prefix, T, B, e.max().item())
+                assert (outs[0][1] - outs[1][1]).abs().max().item() <= 2e-2 and torch.isfinite(outs[1][1]).all()
+    finally:
+        rt.set_tuning("static_attn", 1)
+
+
 def test_attention_two_streams_of_different_length(op_rt):
     cfg, _, rt = op_rt
     d = rt.desc
