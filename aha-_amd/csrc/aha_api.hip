@@ -102,6 +102,7 @@ struct aha_ctx {
     long* gen_tok = nullptr; bf16* gen_emb = nullptr; float* gen_tmp = nullptr; int* gen_nhist = nullptr; long* gen_out = nullptr;
     long* gen_pin = nullptr; hipEvent_t gen_ev = nullptr; int gen_cap = 0;
     // operator-level attention (aha_attention_forward): its own descriptor slot ring is the step's (sd_pin / sd_dev)
+    int pool_subset = 1;                 // projector only on the patch rows bilinear pooling samples (tuning "pool_subset"; bit-identical)
     int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
@@ -294,6 +295,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;
     else if (k == "static_attn") c->static_attn = value;
+    else if (k == "pool_subset") c->pool_subset = value;
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
@@ -811,6 +813,18 @@ extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* ou
     // cheaper than compacting) and the pooling reads the Np patch rows of each frame's Tt.
     const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
+    // Bilinear pooling with an even integer stride samples only 4 go^2 of the g^2 patch rows, with weights 1/2: run the
+    // projector on those rows only and pool the compact (2 go)^2 grid - same values, same arithmetic, bit-identical embeddings
+    // (elementwise.hip: gather_pool_rows_kernel; tuning "pool_subset").  24 -> 6: 144 of 576 rows, 75 % of the projector saved.
+    const int s = c->go > 0 ? c->grid / c->go : 0;
+    if (c->pool_subset && d.pool_mode == 0 && c->go > 0 && c->grid % c->go == 0 && s >= 4 && s % 2 == 0) {
+        const int gc = 2 * c->go, crow = n * gc * gc;
+        HIPCHK(c, aha_gather_pool_rows(c->v_x, c->v_h, n, c->grid, c->go, s, Dv, c->Tt, st));       // v_h: free after the tower
+        HIPCHK(c, tile_gemm(c->v_h, Dv, crow, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, tile_gemm(c->v_p1, H, crow, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+        HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, gc, c->go, H, 2, 0, gc * gc, st));
+        return 0;
+    }
     HIPCHK(c, tile_gemm(c->v_x, Dv, rows, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, rows, c->p2w, H, H, H, c->v_p2, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, aha_pool(c->v_p2, (bf16*)out_embeds, n, c->grid, c->go, H, d.pool_stride, d.pool_mode, c->Tt, st));

@@ -544,6 +544,23 @@ __global__ void pool_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
     *reinterpret_cast<bf16x8*>(out + cell * H + hc * 8) = o;
 }
 
+// Rows of the tower output that bilinear pooling g -> go actually samples, compacted to a (2 go) x (2 go) grid per frame.
+// With an even integer stride s = g / go and align_corners = False the source coordinate of output cell o is s*o + s/2 - 1/2:
+// rows s*o + s/2 - 1 and s*o + s/2 with weights exactly 1/2 - so the projector (two GEMMs, 19 GFLOP per frame at full size)
+// needs only 4 go^2 of the g^2 patch rows (144 of 576 at 24 -> 6), and pooling the compact grid 2 go -> go reproduces the same
+// arithmetic on the same values (stride 2: rows 2o, 2o + 1, weights 1/2): bit-identical embeddings.
+__global__ void gather_pool_rows_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int g, int go, int s, int Dv,
+                                        int frame_rows) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dch = Dv >> 3, gc = 2 * go;
+    if (gid >= (long)N * gc * gc * dch) return;
+    const int c = (int)(gid % dch);
+    const long cell = gid / dch;
+    const int cx = (int)(cell % gc), cy = (int)((cell / gc) % gc), n = (int)(cell / ((long)gc * gc));
+    const int y = s * (cy >> 1) + s / 2 - 1 + (cy & 1), x = s * (cx >> 1) + s / 2 - 1 + (cx & 1);
+    *reinterpret_cast<bf16x8*>(out + cell * Dv + c * 8) = *reinterpret_cast<const bf16x8*>(in + ((long)n * frame_rows + (long)y * g + x) * Dv + c * 8);
+}
+
 // Token embedding gather: out[i][:] = table[ids[i]][:]
 __global__ void embed_gather_kernel(const long* __restrict__ ids, int n, const bf16* __restrict__ table, int H, int vocab,
                                     bf16* __restrict__ out, int ldo) {
@@ -727,6 +744,12 @@ hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, b
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st) {
     const long total = (long)N * go * go * (H >> 3);
     hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, N, g, go, H, stride, mode,
+                       frame_rows > 0 ? frame_rows : g * g);
+    return hipGetLastError();
+}
+hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go, int s, int Dv, int frame_rows, hipStream_t st) {
+    const long total = (long)N * 4 * go * go * (Dv >> 3);
+    hipLaunchKernelGGL(gather_pool_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, out, N, g, go, s, Dv,
                        frame_rows > 0 ? frame_rows : g * g);
     return hipGetLastError();
 }

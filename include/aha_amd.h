@@ -98,6 +98,8 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *   "use_graph"       1: replay frozen static-cache steps from a captured HIP graph      "fuse_static" / "fuse_mlp"  experiments
  *   "time_gemm"       bit k: bracket GEMM kind k's launches with HIP events (aha_lm_last_gemm_time); such steps are launched
  *                     directly, not replayed from a graph, so the events are live
+ *   "pool_subset"     1 (default): the projector runs only on the patch rows that bilinear pooling with an even integer stride samples
+ *                     (24 -> 6: 144 of 576 per frame); bit-identical embeddings
  *   "static_attn"     1 (default): frozen TrulyStaticCache steps whose prefix is <= 64 keys run qkv_finish + attention as one launch
  *   "attn_lm"         LM attention kernel for frame-sized steps: 0 attn_fwd_kernel always, 1 auto (default), 2 attn_lm_kernel always
  *   "use_wl"          1 (default): row chunks above 128 use the mid-M GEMM kernel (both operands staged through LDS); 0: never.

@@ -825,3 +825,19 @@ def test_graph_replay_serves_every_cache_policy_bit_identically(tiny128, bench_r
             st.close()
         rtb.set_tuning("use_graph", 1)
         assert torch.equal(res[0], res[1])
+
+
+def test_projector_on_pooled_rows_only_is_bit_identical(tiny128, bench_rt):
+    """Bilinear pooling 24 -> 6 (stride 4, align_corners=False) reads 2 x 2 source patches per output cell with weights 1/2,
+    i.e. 144 of a frame's 576 patch rows.  By default the projector runs on those rows only (tuning pool_subset); the
+    embeddings must not change by one bit against the full-grid evaluation (the reference's order: project every patch,
+    then pool; video_head_live_llava_qwen.py:107-136).  tiny128's 6 -> 3 grid (stride 2) has no unused rows and takes the
+    full path either way."""
+    for cfg, rt in ((tiny128[0], tiny128[2]), bench_rt):
+        fr = make_frames(3, cfg.vision.image_size, seed=33).cuda()
+        outs = []
+        for mode in (0, 1):
+            rt.set_tuning("pool_subset", mode)
+            outs.append(rt.visual_embed(fr).clone())
+        rt.set_tuning("pool_subset", 1)
+        assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[1].float()).all()
