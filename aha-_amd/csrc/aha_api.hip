@@ -557,7 +557,7 @@ extern "C" int aha_stream_reset(aha_stream* s) {
 extern "C" int aha_stream_seq_length(const aha_stream* s) { return s ? s->len : AHA_E_INVAL; }
 extern "C" int aha_stream_seen_tokens(const aha_stream* s) { return s ? s->seen : AHA_E_INVAL; }
 extern "C" int aha_stream_set_attn_semantics(aha_stream* s, int sem) {
-    if (!s || (sem != AHA_ATTN_TRAILING && sem != AHA_ATTN_HF449_SDPA)) return AHA_E_INVAL;
+    if (!s || (sem != AHA_ATTN_TRAILING && sem != AHA_ATTN_HF449_SDPA && sem != AHA_ATTN_FA2)) return AHA_E_INVAL;
     s->semantics = sem;
     return 0;
 }
@@ -645,7 +645,10 @@ static int plan_stream(aha_ctx* c, aha_stream* s, int T, StreamStep* o) {
     o->ring_head = new_head;
     o->len_after = new_len;
     if (s->policy == AHA_CACHE_STATIC)
-        o->causal_off = (L == 0) ? 0 : (1 << 29);                  // first call: plain causal; frozen: all visible
+        // first call: plain causal.  Frozen: the cache returns the prefix only; sdpa-style masks make all of it visible,
+        // flash-attn-2 (the reference's default attn_implementation, models/arguments_live.py:30) aligns its causal mask bottom-right:
+        // key j visible to new token t iff j <= t + (L - T)
+        o->causal_off = (L == 0) ? 0 : (s->semantics == AHA_ATTN_FA2 ? L - T : (1 << 29));
     else if (s->semantics == AHA_ATTN_HF449_SDPA)
         o->causal_off = L;                                         // key j visible iff j <= L_before + t
     else

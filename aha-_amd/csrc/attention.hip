@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDes
 
     // o[dt][e] <-> d = dt*16 + 4*q4 + e of row r
     if (a.n_splits == 1) {
-        const float inv = 1.0f / l_run;
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;        // a row that sees no key (flash-attn-2 mask of a frozen static cache) gives 0
         bf16* op = a.out + b * a.o_bs + (long)t * a.ldo + head * a.hd + 4 * q4;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         if (!row_ok[tt]) continue;
-        const float inv = 1.0f / l;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
         bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * a.hd + 4 * q4;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64 * NW) void attn_lm_kernel(AttnArgs a, const Step
         l += __shfl_xor(l, 32, 64);
         if (!row_ok[tt]) continue;
         if (a.n_splits == 1) {
-            const float inv = 1.0f / l;
+            const float inv = l > 0.f ? 1.0f / l : 0.f;               // a row that sees no key gives 0
             bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * D + 4 * q4;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
     for (int s = 0; s < ns; ++s) {
         const long prow = (base + s) * Rpad + r;
-        const float w = __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // attn_lm_kernel keeps its running maxima in the base-2 domain
+        const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima live in the base-2 domain
         L += w * a.part_ml[prow * 2 + 1];
         const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0), p1 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
 #pragma unroll
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     const int g = r / a.T, t = r % a.T;
     bf16x8 ov;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[e] / L);
+    for (int e = 0; e < 8; ++e) ov[e] = f2bf(L > 0.f ? acc[e] / L : 0.f);
     *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
 }
 
@@ -731,12 +731,12 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
     float acc = 0.f, L = 0.f;
     for (int s = 0; s < ns; ++s) {
         const long prow = (base + s) * Rpad + r;
-        const float w = __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima are kept in the base-2 domain
+        const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima are kept in the base-2 domain
         L += w * a.part_ml[prow * 2 + 1];
         acc += w * a.part_o[prow * D + d];
     }
     const int g = r / a.T, t = r % a.T;
-    if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(acc / L);
+    if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(L > 0.f ? acc / L : 0.f);
 }
 
 static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of the dense kernel (0 = auto, 1..3 forced)

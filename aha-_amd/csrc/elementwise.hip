@@ -176,6 +176,9 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
     const StreamStep ss = sdp->s[b];
     const int Lk = min(ss.len_after, LMAX);
     int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
+    // keys 0 .. nvis-1 are visible to this row: all of them under the sdpa-style rule; j <= causal_off + t under flash-attn-2's
+    // bottom-right alignment (causal_off = L - T: the first T - L rows of a frame then see nothing and give 0)
+    const int nvis = max(0, min(Lk, ss.causal_off > (1 << 28) ? Lk : ss.causal_off + t + 1));
 
     // ---- the frozen prefix of this KV head -> LDS (issued first: independent of the slab reduce below)
     {
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
         if (i < G * Lk) {
             const int gi = i / Lk;
             float m = -INFINITY;
-            for (int j = 0; j < Lk; ++j) m = fmaxf(m, ps[gi * LMAX + j]);
-            pj[u] = __builtin_amdgcn_exp2f(__builtin_fmaf(ps[gi * LMAX + i % Lk], c2, -m * c2));
+            for (int j = 0; j < nvis; ++j) m = fmaxf(m, ps[gi * LMAX + j]);
+            pj[u] = (i % Lk) < nvis ? __builtin_amdgcn_exp2f(__builtin_fmaf(ps[gi * LMAX + i % Lk], c2, -m * c2)) : 0.f;
         }
     }
     __syncthreads();
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(pb, bf2f(vv[e]), acc[e]);
         }
-        const float inv = 1.0f / l;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
         bf16x4 o = {f2bf(acc[0] * inv), f2bf(acc[1] * inv), f2bf(acc[2] * inv), f2bf(acc[3] * inv)};
         *reinterpret_cast<bf16x4*>(p.out + (long)row * p.ldo + (hk * G + g) * D + dd) = o;
     }

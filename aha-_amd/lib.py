@@ -31,7 +31,7 @@ class TensorView(C.Structure):
 
 
 CACHE_NONE, CACHE_SINK, CACHE_SLIDING, CACHE_STATIC = 0, 1, 2, 3
-ATTN_TRAILING, ATTN_HF449_SDPA = 0, 1
+ATTN_TRAILING, ATTN_HF449_SDPA, ATTN_FA2 = 0, 1, 2
 
 # every symbol include/aha_amd.h declares: (name, restype, argtypes)
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float

@@ -57,8 +57,8 @@ class Stream:
         rt._chk(rt.lib.aha_stream_open(rt.ctx, self.policy, window_length, num_sink_tokens, capacity, C.byref(h)))
         self.handle = h
         rt._streams.add(self)
-        if attn_semantics != "trailing":
-            rt._chk(rt.lib.aha_stream_set_attn_semantics(h, _l.ATTN_HF449_SDPA))
+        if attn_semantics != "trailing":            # "hf449_sdpa": transformers-4.49 sdpa mask arithmetic; "fa2": flash-attn-2 alignment
+            rt._chk(rt.lib.aha_stream_set_attn_semantics(h, {"hf449_sdpa": _l.ATTN_HF449_SDPA, "fa2": _l.ATTN_FA2}[attn_semantics]))
 
     def reset(self):
         self.rt._chk(self.rt.lib.aha_stream_reset(self.handle))

@@ -68,8 +68,11 @@ enum { AHA_CACHE_NONE = 0,      /* past_key_values=None -> growing DynamicCache 
        AHA_CACHE_STATIC = 3 };  /* test/static_cache.py TrulyStaticCache(window_size)      */
 
 /* Attention-mask arithmetic (DESIGN.md "Mask semantics"): 0 = trailing-causal (parity target of
- * SURVEY.md 8c), 1 = transformers-4.49 sdpa mask arithmetic. */
-enum { AHA_ATTN_TRAILING = 0, AHA_ATTN_HF449_SDPA = 1 };
+ * SURVEY.md 8c), 1 = transformers-4.49 sdpa mask arithmetic, 2 = flash-attn-2 (the reference's default
+ * attn_implementation, models/arguments_live.py:30): bottom-right aligned causal mask - equal to 0 for every
+ * cache policy except a frozen TrulyStaticCache, where new token t sees prefix key j iff j <= t + (L - T)
+ * (rows that see no key give 0).  The scores the drivers read (position -1) are the same under 0 and 2. */
+enum { AHA_ATTN_TRAILING = 0, AHA_ATTN_HF449_SDPA = 1, AHA_ATTN_FA2 = 2 };
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* replaces build_model_and_tokenizer()/build_live() model construction

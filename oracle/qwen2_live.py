@@ -22,6 +22,15 @@ with cos/sin; positions = ``cache.get_seq_length()`` + arange(T); attention mask
       the returned key length).  Equals "trailing" while the cache grows; once a sink or
       sliding window is full it lets a new token see later tokens of its own chunk.
 
+  attn_semantics="fa2": flash-attn-2, the reference's default attn_implementation
+      (models/arguments_live.py:30): causal mask aligned to the bottom-right corner of the
+      [T, Lk] score matrix, key j visible to new token i iff j <= i + (Lk - T).  Equal to
+      "trailing" whenever the policy returns the new keys; for a frozen StaticPolicy (prefix
+      only) the first T - Lk new tokens see no key at all and flash-attn returns 0 for them.
+      The last token sees every prefix key under both rules, and under a frozen static cache a
+      token's hidden state depends on no other new token, so the scores the drivers read at
+      position -1 are identical under "trailing" and "fa2".
+
 Pinned by tests/test_oracle_models.py against local transformers Qwen2Model + DynamicCache
 (live, and through tests/golden/qwen2_tiny_steps.npz).
 """
@@ -61,7 +70,7 @@ class OracleLM:
         self.w = {k: v.to(dtype) for k, v in weights.items()
                   if k.startswith(("model.", "lm_head", "informative_head", "relevance_head",
                                    "uncertainty_head"))}
-        assert attn_semantics in ("trailing", "hf449_sdpa")
+        assert attn_semantics in ("trailing", "hf449_sdpa", "fa2")
         self.attn_semantics = attn_semantics
         self.attn_impl = attn_impl
         # PEFT LoRA adapters, UNMERGED as the reference runs them (PeftModel.from_pretrained, models/modeling_live.py:171-179;
@@ -103,8 +112,8 @@ class OracleLM:
         Lk = K.shape[-2]
         # visibility: key j visible to new token t iff j <= off + t
         if static_frozen:
-            off = Lk                                    # everything visible
-        elif self.attn_semantics == "trailing":
+            off = Lk - T if self.attn_semantics == "fa2" else Lk     # fa2: bottom-right aligned; else everything visible
+        elif self.attn_semantics in ("trailing", "fa2"):
             off = Lk - T
         else:
             off = L_before
@@ -122,6 +131,9 @@ class OracleLM:
             aw = aw + torch.where(mask, 0.0, torch.finfo(aw.dtype).min)[None, None].to(aw.dtype)
             aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
             o = torch.matmul(aw, Vr)
+        dead = ~mask.any(dim=-1)                        # rows that see no key (fa2 + frozen static): flash-attn gives 0, not NaN
+        if dead.any():
+            o = torch.where(dead[None, None, :, None], torch.zeros_like(o), o)
         o = o.transpose(1, 2).reshape(B, T, -1)
         if tr is not None:
             tr.update(attn_out=o, K=K, V=V)

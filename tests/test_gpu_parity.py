@@ -841,3 +841,34 @@ def test_projector_on_pooled_rows_only_is_bit_identical(tiny128, bench_rt):
             outs.append(rt.visual_embed(fr).clone())
         rt.set_tuning("pool_subset", 1)
         assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[1].float()).all()
+
+
+@pytest.mark.parametrize("which", ["tiny", "tiny128"])
+def test_flash_attn2_static_mask_mode(which, request):
+    """AHA_ATTN_FA2: the frozen TrulyStaticCache step under flash-attn-2's bottom-right mask (rows that see no key give 0).
+    Every position's head outputs against the oracle run with the same semantics; the last position's scores equal the
+    default semantics' bit for bit (it sees the whole prefix under both); prefixes of 5 keys (fused short-prefix kernel,
+    rows without keys) and 70 keys (tile kernels)."""
+    from oracle.cache_policies import make_policy
+    from oracle.qwen2_live import OracleLM
+    cfg, w, rt = request.getfixturevalue(which)
+    H = cfg.lm.hidden_size
+    o = OracleLM(cfg.lm, w, torch.bfloat16, attn_semantics="fa2")
+    g = torch.Generator().manual_seed(44)
+    for n_prefix, T in ((5, 9), (70, 9), (70, 90)):
+        pre = (torch.randn(1, n_prefix, H, generator=g) * 0.5).bfloat16()
+        x = (torch.randn(1, T, H, generator=g) * 0.5).bfloat16()
+        pol = make_policy("static", 128, 0)
+        o.step(pre, pol)
+        want = o.step(x, pol)
+        sf, sd = rt.open_stream("static", 128, 0, attn_semantics="fa2"), rt.open_stream("static", 128, 0)
+        rt.lm_step([sf], pre.cuda()), rt.lm_step([sd], pre.cuda())
+        got_d = rt.lm_step([sd], x.cuda()).cpu()
+        got_f = rt.lm_step([sf], x.cuda()).cpu()
+        raw = rt.heads_all(1, T).cpu()
+        hid = rt.last_hidden_all(1, T).float().cpu()
+        assert torch.equal(got_d, got_f) and torch.isfinite(raw).all()
+        assert (hid - want["hidden"].float()).abs().max().item() <= 0.12
+        assert (raw[..., :2] - want["informative_logits"]).abs().max().item() <= 0.03
+        assert (raw[..., 3:4] - want["uncertainty"]).abs().max().item() <= 0.03
+        sf.close(), sd.close()

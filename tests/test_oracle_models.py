@@ -169,3 +169,33 @@ def test_static_frozen_sees_prefix_only():
     o.step(prefix, c1), o.step(prefix, c2)
     o.step(a, c1)
     assert torch.equal(o.step(b, c1)["hidden"], o.step(b, c2)["hidden"])
+
+
+def test_flash_attn2_mask_semantics_of_the_oracle():
+    """attn_semantics="fa2" (the reference's default attn_implementation, models/arguments_live.py:30): bottom-right aligned
+    causal mask.  It equals the trailing rule for every policy that returns the new keys; under a frozen TrulyStaticCache the
+    first T - L new tokens see no key (output 0, finite), the other rows differ from the all-visible rule, and the scores the
+    drivers read at position -1 are identical."""
+    import torch
+    from aha_amd.config import preset
+    from aha_amd.synth import make_weights
+    from oracle.cache_policies import make_policy
+    from oracle.qwen2_live import OracleLM, frame_scores
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    g = torch.Generator().manual_seed(0)
+    pre = torch.randn(1, 5, cfg.lm.hidden_size, generator=g) * 0.5
+    xs = [torch.randn(1, 9, cfg.lm.hidden_size, generator=g) * 0.5 for _ in range(3)]
+    for policy in ("static", "default_sink", None):
+        outs = {}
+        for sem in ("trailing", "fa2"):
+            o = OracleLM(cfg.lm, w, torch.float32, attn_semantics=sem)
+            pol = make_policy(policy, 16, 2)
+            o.step(pre, pol)
+            outs[sem] = [o.step(x, pol) for x in xs]
+        for a, b in zip(outs["trailing"], outs["fa2"]):
+            assert torch.equal(frame_scores(a), frame_scores(b)) and torch.isfinite(b["hidden"]).all()
+            if policy == "static":
+                assert not torch.equal(a["hidden"][:, 0], b["hidden"][:, 0])          # row 0 sees nothing under fa2 (9 new tokens, 5 keys)
+            else:
+                assert torch.equal(a["hidden"], b["hidden"])
