@@ -293,8 +293,9 @@ static __device__ __forceinline__ void rerotate_store4(bf16* kp, bf16x4 x1, bf16
 
 template <int D>
 __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __restrict__ sdp, unsigned stream_mask,
-                                                            const bf16* __restrict__ rcos, const bf16* __restrict__ rsin,
+                                                            const void* __restrict__ rcos_, const void* __restrict__ rsin_,
                                                             int layers, int Hkv) {
+    const bf16 *rcos = static_cast<const bf16*>(rcos_), *rsin = static_cast<const bf16*>(rsin_);
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
     const int b = blockIdx.z;
     if (!((stream_mask >> b) & 1u)) return;                 // streams that share this launch's (W, sink, T) table
@@ -316,9 +317,11 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
 // grid: (max(n_rerot, T) key blocks, Hkv); new K/V: bf16 [Hkv][T][D] (already rotated, as the reference's attention hands
 // them to Cache.update, test/sink_cache.py:74-80).
 template <int D>
-__global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, int layer, int Hkv, int T, const bf16* __restrict__ knew,
-                                                                 const bf16* __restrict__ vnew, const bf16* __restrict__ rcos,
-                                                                 const bf16* __restrict__ rsin) {
+__global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, int layer, int Hkv, int T, const void* __restrict__ knew_,
+                                                                 const void* __restrict__ vnew_, const void* __restrict__ rcos_,
+                                                                 const void* __restrict__ rsin_) {
+    const bf16 *knew = static_cast<const bf16*>(knew_), *vnew = static_cast<const bf16*>(vnew_);
+    const bf16 *rcos = static_cast<const bf16*>(rcos_), *rsin = static_cast<const bf16*>(rsin_);
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
     const int hk = blockIdx.y;
     const int key = blockIdx.x * KPB + threadIdx.x / IPK;
@@ -351,9 +354,13 @@ __global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, 
 // torch evaluates each product and each sum as its own fp32 op, so contraction into FMAs is switched off here
 // (checked in the ISA: v_mul_f32 / v_add_f32 only).
 // ---------------------------------------------------------------------------------------------
-__global__ void rerot_table_kernel(const bf16* __restrict__ cosb, const bf16* __restrict__ sinb, int D, int sink, int T, int rows,
-                                   bf16* __restrict__ rc, bf16* __restrict__ rs) {
+// (kernel parameters that are raw bf16 pointers are passed as void*: rocprofv3's counter-collection mode crashed on kernels whose
+// mangled names carry the bf16 type outside a struct - it could not demangle them)
+__global__ void rerot_table_kernel(const void* __restrict__ cosb_, const void* __restrict__ sinb_, int D, int sink, int T, int rows,
+                                   void* __restrict__ rc_, void* __restrict__ rs_) {
 #pragma clang fp contract(off)
+    const bf16 *cosb = static_cast<const bf16*>(cosb_), *sinb = static_cast<const bf16*>(sinb_);
+    bf16 *rc = static_cast<bf16*>(rc_), *rs = static_cast<bf16*>(rs_);
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)rows * D) return;
     const int i = (int)(gid / D), d = (int)(gid % D);

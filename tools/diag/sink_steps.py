@@ -12,10 +12,10 @@ cfg = preset("bench"); tf, H = cfg.frame_num_tokens, cfg.lm.hidden_size
 w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
 rt = Runtime(cfg, w, max_step_tokens=640, max_vit_frames=8)
 del w
-rt.set_tuning("use_graph", 0)
+rt.set_tuning("use_graph", int(sys.argv[2]) if len(sys.argv) > 2 else 0)      # direct launches by default (per-kernel trace rows); 1: graph replay
 g = torch.Generator(device="cuda").manual_seed(0)
 sts = [rt.open_stream("default_sink", 2048, 32) for _ in range(B)]
 x = (torch.randn(B, tf, H, generator=g, device="cuda") * 0.05).bfloat16()
-for _ in range(70):
+for _ in range(64):
     rt.lm_step(sts, x)
 torch.cuda.synchronize()
