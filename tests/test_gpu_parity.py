@@ -872,3 +872,41 @@ def test_flash_attn2_static_mask_mode(which, request):
         assert (raw[..., :2] - want["informative_logits"]).abs().max().item() <= 0.03
         assert (raw[..., 3:4] - want["uncertainty"]).abs().max().item() <= 0.03
         sf.close(), sd.close()
+
+
+def test_timed_steps_bypass_graph_replay_and_lifetime_rules(tiny128):
+    """(1) With a GEMM kind being timed a step is launched directly (a plain hipEventRecord issued during capture is not a
+    graph node, so replayed steps would leave the events stale): two consecutive timed steps under use_graph = 1 both report
+    all their launches with positive, fresh times, and the scores equal the replayed ones.  (2) A second aha_ctx_load_weights
+    is refused instead of leaking the first set.  (3) Streams may outlive their Runtime (aha_stream_destroy does not touch
+    the context) and Runtime.close() closes the streams it still tracks."""
+    from aha_amd.runtime import AhaError, Runtime
+    cfg, w, rt = tiny128
+    H, tf = cfg.lm.hidden_size, cfg.frame_num_tokens
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1, tf, H, generator=g) * 0.3).bfloat16().cuda()
+    st = rt.open_stream("static", 64, 0)
+    rt.lm_step([st], x[:, :5].contiguous())
+    ref = [rt.lm_step([st], x).clone() for _ in range(4)][-1]          # replayed from a graph by now
+    rt.set_tuning("time_gemm", 1 << 2)
+    times = []
+    for _ in range(2):
+        got = rt.lm_step([st], x).clone()
+        torch.cuda.synchronize()
+        ms, n, by = rt.last_gemm_time(2)
+        assert n == cfg.lm.num_hidden_layers and ms > 0 and by > 0
+        assert torch.equal(got, ref)
+        times.append(ms)
+    rt.set_tuning("time_gemm", 0)
+    rt.lm_step([st], x)
+    assert rt.last_gemm_time(2)[1] == 0                                # untimed (replayed) steps record nothing
+    st.close()
+    with pytest.raises(AhaError):
+        rt._load(w)                                                    # second load into the same context
+    rt2 = Runtime(cfg, w, max_step_tokens=64, max_vit_frames=2, max_positions=1024)
+    s_a, s_b = rt2.open_stream("default_sink", 32, 4), rt2.open_stream(None, capacity=64)
+    rt2.lm_step([s_a, s_b], x.expand(2, -1, -1).contiguous())
+    torch.cuda.synchronize()
+    rt2.close()                                                        # closes both streams
+    assert s_a.handle is None and s_b.handle is None
+    s_a.close()                                                        # idempotent
