@@ -301,7 +301,8 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_lm") aha_attention_set_lm_kernel(value);   // 1 (default): frame-sized LM steps use attn_lm_kernel (LDS-DMA, all row tiles per workgroup)
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
-    else if (k == "tile_dma") aha_gemm_tile_set_dma(value);      // 0 off, 1 auto (default), 2 force
+    else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
+    else if (k == "tile_epi") aha_gemm_tile_set_epi(value);      // 1 (default): LDS-transposed wide epilogue of the LDS-DMA tile kernels      // 0 off, 1 auto (default), 2 force
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
     return 0;
 }

@@ -28,6 +28,7 @@ struct GemmTileArgs {
     int act;
     const bf16* residual; int ldr;   // out = bf16(residual + bf16(lin)); may alias C
     const bf16* rowadd; int rowadd_period, ldra;  // out = bf16(bf16(lin) + rowadd[m % period]) (position embedding)
+    int wide_epi;               // set by aha_gemm_tile (tuning "tile_epi"): LDS-transposed 16-byte epilogue of the LDS-DMA kernels
 };
 
 struct AttnArgs {
@@ -92,6 +93,7 @@ hipError_t aha_gemm_wl(const GemmWsArgs* a, int epi, hipStream_t st);
 hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, int tile_stride, int tile_off, hipStream_t st);
 hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);
+void aha_gemm_tile_set_epi(int on);
 void aha_gemm_ws_set_kc_small(int v);
 void aha_attention_set_dense_tpw(int v);
 void aha_attention_set_lm_kernel(int v);

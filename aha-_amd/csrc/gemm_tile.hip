@@ -170,6 +170,69 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmTileArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue of the LDS-DMA kernels through LDS (round 2).  The accumulator layout gives a lane 4 consecutive output columns
+// of one row per 16x16 tile, so a direct store is 16 (WI x WJ) wave-instructions of 8 B per lane, each touching 16 rows with
+// 32 B: quarter cache lines, store-issue-bound.  The K sweep of tools/diag/tile_ablate.py put the FIXED cost of a 256x128
+// workgroup (fill + this epilogue) at 8-12 us against 5.6-7.6 us per 64 of K - a third of the K = 1024 tower GEMMs.
+// Here a wave first writes its finished bf16 tile (bias and activation applied: same rounding points) row-major into the
+// stage memory, which is free once the k-loop has drained, and then moves it out in full 128-byte rows, 16 B per lane
+// (8 rows per wave-instruction), adding the residual / row-add operand on the way with equally wide loads.  One rounding per
+// step exactly as before, so every variant stays bit-identical to gemm_tile_kernel.
+// Requirements (checked by the caller): N % 8 == 0, ldc % 8 == 0, ldr / ldra % 8 == 0 - otherwise the direct epilogue runs.
+// ---------------------------------------------------------------------------------------------
+template <int WI, int WJ>
+static __device__ __forceinline__ void tile_epilogue_lds(const GemmTileArgs& g, f32x4 (&acc)[WI][WJ], bf16* stg, const int mw, const int nw,
+                                                         const int lane) {
+    constexpr int COLS = 16 * WJ, ST = COLS + 8, CPR = COLS / 8;      // staging row stride padded by 16 B; 16-B chunks per row
+    const int q = lane >> 4, r16 = lane & 15;
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int n = min(nw + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));            // Linear output (bf16)
+                if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
+                else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
+                o[e] = f2bf(x);
+            }
+            *reinterpret_cast<bf16x4*>(&stg[(i * 16 + r16) * ST + j * 16 + q * 4]) = o;
+        }
+    // the staging area is private to the wave: its own LDS writes only need to have landed (the compiler's lgkmcnt wait)
+    constexpr int ITERS = (16 * WI * CPR) / 64;
+    static_assert((16 * WI * CPR) % 64 == 0, "wave tile must split into whole 1-KiB store instructions");
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
+        const int m = mw + row, n = nw + ch * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(&stg[row * ST + ch * 8]);
+        const int mc = min(m, g.M - 1), nc = min(n, g.N - 8);
+        bf16x8 rv, pv;
+        if (g.residual) rv = *reinterpret_cast<const bf16x8*>(g.residual + (long)mc * g.ldr + nc);
+        if (g.rowadd) pv = *reinterpret_cast<const bf16x8*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + nc);
+        if (g.residual)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(rv[e]) + bf2f(v[e])));
+        if (g.rowadd)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(v[e]) + bf2f(pv[e])));
+        if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;
+    }
+}
+static __device__ __forceinline__ bool tile_epilogue_wide_ok(const GemmTileArgs& g) {
+    return g.wide_epi && !(g.N & 7) && !(g.ldc & 7) && (!g.residual || !(g.ldr & 7)) && (!g.rowadd || !(g.ldra & 7));
+}
+
+// ---------------------------------------------------------------------------------------------
 // LDS-DMA family (K % 64 == 0): block tile BM x BN = (WAVES_M*16*WI) x (WAVES_N*16*WJ), one wave per
 // (16*WI) x (16*WJ) sub-tile, STAGES stages of (BM+BN) 128-byte rows filled by global_load_lds_dwordx4
 // (no staging VGPRs, so STAGES-1 k-tiles are in flight while one computes - the register-staged kernel
@@ -324,7 +387,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tile_dma_kernel(G
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
 
-    // epilogue (same rounding points as gemm_tile_kernel)
+    if (tile_epilogue_wide_ok(g)) {                                // uniform
+        __builtin_amdgcn_s_barrier();                              // every wave is done reading the stages: they become staging
+        tile_epilogue_lds<WI, WJ>(g, acc, lds + wave * (16 * WI * (16 * WJ + 8)), m0 + wm * (16 * WI), n0 + wn * (16 * WJ), lane);
+        return;
+    }
+    // direct epilogue (same rounding points as gemm_tile_kernel)
     const bf16x4 z4 = {0, 0, 0, 0};
     bf16x4 bv[WJ];
 #pragma unroll
@@ -463,6 +531,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (tile_epilogue_wide_ok(g)) {                                // uniform
+        __builtin_amdgcn_s_barrier();
+        tile_epilogue_lds<WI, WJ>(g, acc, lds + wave * (16 * WI * (16 * WJ + 8)), m0 + wm * (16 * WI), n0 + wn * (16 * WJ), lane);
+        return;
+    }
     const bf16x4 z4 = {0, 0, 0, 0};
     bf16x4 bv[WJ];
 #pragma unroll
@@ -506,6 +579,7 @@ template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
 static hipError_t launch_dma32(const GemmTileArgs* g, hipStream_t st) {
     constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
     constexpr int lds_bytes = STAGES * (BM + BN) * 32 * 2;
+    static_assert(lds_bytes >= WAVES_M * WAVES_N * 16 * WI * (16 * WJ + 8) * 2, "stage ring must hold the epilogue staging image");
     static bool attr_set = false;
     auto kern = gemm_tile_dma32_kernel<WI, WJ, WAVES_M, WAVES_N, STAGES>;
     if (!attr_set) {
@@ -714,12 +788,15 @@ static hipError_t launch_256(const GemmTileArgs* g, hipStream_t st) {
 // tuning "tile_dma": 0 disables the LDS-DMA family, 1 auto, >= 2 forces variant id (tests, sweeps) whenever K allows
 static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
+static int g_tile_epi = 1;       // tuning "tile_epi": 1 = LDS-transposed wide epilogue (default), 0 = direct 8-byte stores
+extern "C" void aha_gemm_tile_set_epi(int on) { g_tile_epi = on; }
 
 template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES, bool ILV = false>
 static hipError_t launch_dma(const GemmTileArgs* g, hipStream_t st) {
     constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
     constexpr int lds_bytes = STAGES * (BM + BN) * TBK * 2;
     static_assert(lds_bytes <= 160 * 1024, "stage ring exceeds the CU's LDS");
+    static_assert(lds_bytes >= WAVES_M * WAVES_N * 16 * WI * (16 * WJ + 8) * 2, "stage ring must hold the epilogue staging image");
     static bool attr_set = false;
     auto kern = gemm_tile_dma_kernel<WI, WJ, WAVES_M, WAVES_N, STAGES, ILV>;
     if (!attr_set) {
@@ -754,7 +831,10 @@ static hipError_t check_tile_args(const GemmTileArgs* g) {
     return hipSuccess;
 }
 
-extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st) {
+extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
+    GemmTileArgs gg = *g_;
+    gg.wide_epi = g_tile_epi;
+    const GemmTileArgs* g = &gg;
     if (g->M <= 0 || g->N <= 0) return hipSuccess;
     if (hipError_t e = check_tile_args(g); e != hipSuccess) return e;
     const int nblk128 = ceil_div(g->N, 128) * ceil_div(g->M, 128);

@@ -12,9 +12,11 @@ w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
 for nmax in (32, 64, 128):
     rt = Runtime(cfg, w, max_step_tokens=64, max_vit_frames=nmax)
     fr = make_frames(nmax, cfg.vision.image_size, seed=1).cuda()
-    for _ in range(2): rt.visual_embed(fr)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(5): rt.visual_embed(fr)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
-    print(f"batch {nmax}: {dt*1e3:.2f} ms = {dt*1e3/nmax*32:.2f} ms per 32 frames", flush=True)
+    for epi in (0, 1, 0, 1):
+        rt.set_tuning("tile_epi", epi)
+        for _ in range(2): rt.visual_embed(fr)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): rt.visual_embed(fr)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+        print(f"batch {nmax} tile_epi={epi}: {dt*1e3:.2f} ms = {dt*1e3/nmax*32:.2f} ms per 32 frames", flush=True)
     rt.close()
