@@ -96,6 +96,9 @@ struct aha_ctx {
     int wpb[GK_GEMMS] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
+    int act_kb = 2;                                         // tuning: k-blocked SwiGLU activation between the mid-M gate/up and down GEMMs
+    int act_kb_rows = 0;                                    // rows of the k-blocked activation the last step left in c->act (0: row-major)
+    int dev_xkb = 0;                                        // experiment: aha_linear_forward reads X k-blocked ([K/32][ldx rows][32])
     int use_wl = 1;                                         // tuning: mid-M GEMM kernel (gemm_wl.hip) for row chunks above 128 (0: gemm_ws everywhere)
     int layer_first = 0, layer_count = 0;                   // tuning: run only decoder layers [first, first+count) (0 = all); parity taps
     // generation scratch (aha_generate_greedy): next-token id, embedding row, penalty temporaries, device history count, host poll slot
@@ -291,6 +294,8 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "attn_split_len") c->attn_split_len = value;
     else if (k == "time_gemm") c->time_gemm = value;
     else if (k == "use_wl") c->use_wl = value;
+    else if (k == "dev_xkb") c->dev_xkb = value;
+    else if (k == "act_kb") c->act_kb = value;
     else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
     else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;
@@ -918,7 +923,20 @@ static GemmWsArgs ws_args(const bf16* X, int ldx, int M, int m0, int mrows, cons
 // output element's k-steps in the same order with the same split-K slices, so the choice never changes a bit.
 static int ws_row_chunk(const aha_ctx* c, int epi, int M, int K) {
     const bool wl_ok = c->use_wl && M > 128 && (epi == EPI_PARTIAL || epi == EPI_SWIGLU) && K % 32 == 0;
-    return wl_ok ? 320 : aha_gemm_ws_max_m(epi);
+    if (!wl_ok) return aha_gemm_ws_max_m(epi);
+    // even chunks of whole row tiles, so that every chunk of an M > 128 step stays in the mid-M kernel's range (129..320)
+    const int n = ceil_div(M, 320);
+    return round_up(ceil_div(M, n), 16);
+}
+// Every row chunk of this GEMM runs gemm_wl (what a k-blocked operand layout needs: gemm_ws reads row-major X only).
+static bool ws_all_wl(const aha_ctx* c, int epi, int M, int K) {
+    if (!(c->use_wl && M > 128 && (epi == EPI_PARTIAL || epi == EPI_SWIGLU) && K % 32 == 0)) return false;
+    const int mmax = ws_row_chunk(c, epi, M, K);
+    for (int m0 = 0; m0 < M; m0 += mmax) {
+        const int rows = (M - m0 < mmax) ? M - m0 : mmax;
+        if (rows <= 128 || rows > 320) return false;
+    }
+    return true;
 }
 static hipError_t ws_or_wl(const aha_ctx* c, const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
     if (c->use_wl && aha_gemm_wl_supports(a, epi)) return aha_gemm_wl(a, epi, st);
@@ -944,12 +962,16 @@ static int timed_end(aha_ctx* c, int kind, double bytes, hipStream_t st) {
 }
 
 static int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
-                   bf16* out, int ldo, float* outf, int ldof, hipStream_t st) {
+                   bf16* out, int ldo, float* outf, int ldof, hipStream_t st, int kb = 0) {
+    // kb bit 0: X is k-blocked ([K/32][M][32], gemm_wl.hip); bit 1: the SwiGLU output is written k-blocked.  Callers set them
+    // only when ws_all_wl() holds for the GEMMs on both sides of the buffer.
     const int mmax = ws_row_chunk(c, epi, M, w.K);
     const bool timed = kind >= 0 && ((c->time_gemm >> kind) & 1);      // time_gemm: bit k = GEMM kind k
     if (timed) { if (int rc = timed_begin(c, kind, st)) return rc; }
     for (int m0 = 0; m0 < M; m0 += mmax) {
         GemmWsArgs a = ws_args(X, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, w, S, partial, ldp, out, ldo, outf, ldof);
+        if (kb & 1) { a.X = X + (long)m0 * 32; a.xkb = M; }
+        if (kb & 2) { a.out = out + (long)m0 * 32; a.okb = M; }
         HIPCHK(c, ws_or_wl(c, &a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
     }
     if (timed) { if (int rc = timed_end(c, kind, w.bytes() * ceil_div(M, mmax), st)) return rc; }
@@ -1092,6 +1114,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         l_first = c->layer_first < 0 ? 0 : (c->layer_first >= d.layers ? d.layers - 1 : c->layer_first);
         l_end = l_first + c->layer_count > d.layers ? d.layers : l_first + c->layer_count;
     }
+    // layout of the SwiGLU activation this step leaves in c->act (a function of M and the tunings only, so a replayed graph
+    // agrees with it): k-blocked when both MLP GEMMs run the mid-M kernel on every row chunk (the fused MLP block needs M <= 64)
+    c->act_kb_rows = (c->act_kb && I % 32 == 0 && ws_all_wl(c, EPI_SWIGLU, M, H) && ws_all_wl(c, EPI_PARTIAL, M, I)) ? M : 0;
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
@@ -1175,11 +1200,17 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
                 c->last_flops += 2.0 * 16.0 * M * ((double)w.gateup.n_tiles * w.gateup.K + (double)w.down.n_tiles * w.down.K);
             } else {
+                // Between mid-M kernels the operands travel k-blocked ([K/32][M][32]): the consumer's LDS-DMA then pulls
+                // contiguous 1-KiB panels instead of 16 half cache lines per instruction (-16 % on down at M = 288; same bits).
+                // Here: the normed input of gate/up (xkb) and the SwiGLU activation for down_proj (akb).
+                const bool akb = c->act_kb_rows != 0, xkb = akb && c->act_kb >= 2 && H % 32 == 0;
+                ra.xkb = xkb ? M : 0;
                 HIPCHK(c, aha_resid_norm(&ra, M, st));
+                ra.xkb = 0;
                 // gate/up with fused SwiGLU epilogue
-                if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st))) return rc;
+                if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st, (akb ? 2 : 0) | (xkb ? 1 : 0)))) return rc;
                 // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
-                if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+                if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st, akb ? 1 : 0))) return rc;
             }
             ra.S = Sd;
             ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
@@ -1321,7 +1352,12 @@ extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream
         case 1: src = c->xn; cols = c->d.hidden; break;
         case 2: src = c->q_rot; cols = (size_t)c->d.heads * c->d.head_dim; break;
         case 3: src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
-        case 4: src = c->act; cols = c->d.inter; break;
+        case 4:
+            if (c->act_kb_rows) {                                  // the mid-M path leaves the activation k-blocked
+                HIPCHK(c, aha_kblocked_to_rows(c->act, c->act_kb_rows, c->d.inter, (bf16*)out, c->d.inter, st));
+                return 0;
+            }
+            src = c->act; cols = c->d.inter; break;
         default: return fail(c, AHA_E_INVAL, "unknown tap");
     }
     HIPCHK(c, hipMemcpyAsync(out, src, M * cols * 2, hipMemcpyDeviceToDevice, st));
@@ -1380,6 +1416,7 @@ extern "C" int aha_linear_forward(aha_ctx* c, const aha_linear* L, const void* x
                                ldo, epilogue == EPI_BF16 || epilogue == EPI_SWIGLU ? (bf16*)out : nullptr, ldo,
                                epilogue == EPI_F32_RBF ? (float*)out : nullptr, ldo);
         a.bias = (const bf16*)bias;
+        if (c->dev_xkb) { a.xkb = ldx; a.ldx = 32; }
         HIPCHK(c, ws_or_wl(c, &a, epilogue, 4, st));
     }
     return 0;

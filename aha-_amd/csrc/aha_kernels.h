@@ -15,6 +15,8 @@ struct GemmWsArgs {
     float* outf; int ldof;           // EPI_F32_RBF
     const bf16* bias;                // EPI_BF16 optional
     int N;                           // valid output columns (for store guards)
+    int xkb;                         // mid-M kernel only: 0 = X row-major [M][ldx]; else X is k-blocked [K/32][xkb rows][32] (contiguous k-step panels)
+    int okb;                         // mid-M kernel, EPI_SWIGLU only: 0 = out row-major [M][ldo]; else out is k-blocked [N/32][okb rows][32]
 };
 
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_QUICK_GELU = 3 };   // 3: CLIP, x * sigmoid(1.702 x), three bf16 roundings
@@ -52,6 +54,7 @@ struct ResidNormArgs {
     bf16* h; int ldh;
     const bf16* w; bf16* xn; int ldx;
     int H; float eps;
+    int xkb;                         // 0: xn row-major [M][ldx]; else k-blocked [H/32][xkb rows][32] (consumer: the mid-M GEMM)
 };
 
 // fused MLP block (lm_fused.hip): resid_norm -> gate/up + SwiGLU -> down, one launch, two grid barriers
@@ -112,6 +115,7 @@ hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, c
 hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* pos, bf16* x, int n, int Np, int Dv, hipStream_t st);
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st);
+hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go, int s, int Dv, int frame_rows, hipStream_t st);
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);

@@ -763,6 +763,21 @@ hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go,
                        frame_rows > 0 ? frame_rows : g * g);
     return hipGetLastError();
 }
+// k-blocked [K/32][M][32] -> row-major [M][ldo] (parity taps of the mid-M path; 16 B per thread)
+__global__ void kblocked_to_rows_kernel(const bf16* __restrict__ in, int M, int K, bf16* __restrict__ out, int ldo) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece
+    if (i >= (long)M * (K >> 3)) return;
+    const int c = (int)(i & 3);
+    const long rk = i >> 2;
+    const int row = (int)(rk % M), kt = (int)(rk / M);
+    *reinterpret_cast<bf16x8*>(out + (long)row * ldo + kt * 32 + c * 8) = *reinterpret_cast<const bf16x8*>(in + i * 8);
+}
+hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st) {
+    if (K % 32 || ldo % 8) return hipErrorInvalidValue;
+    const long total = (long)M * (K >> 3);
+    hipLaunchKernelGGL(kblocked_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, M, K, out, ldo);
+    return hipGetLastError();
+}
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(256), 0, st, ids, n, table, H, vocab, out, ldo);

@@ -59,14 +59,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
         xblk[i] = min(wave + i * NW, MT - 1);
         const int row = min(xblk[i] * 16 + (lane >> 2), a.M - 1);
         const int c = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
-        xsrc[i] = a.X + (long)row * a.ldx + c * 8;
+        xsrc[i] = a.X + (long)row * (a.xkb ? 32 : a.ldx) + c * 8;
     }
+    const long xkstride = a.xkb ? (long)a.xkb * 32 : 32;            // elements between consecutive k-steps of one row's 64-byte piece
     const bf16* wsrc = reinterpret_cast<const bf16*>(a.Wp + ((long)min(blockIdx.x * NTB + wave, a.n_tiles - 1) * a.KS) * 64 + lane);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto dma = [&](int kt, int stage) {
         const int ks = ks0 + min(kt, nk - 1);                       // past the end: refill a dead stage (keeps the vmcnt counts fixed)
-        const int xk = min(ks, ksx_last) * 32;
+        const long xk = min(ks, ksx_last) * xkstride;
         bf16* sa = lds + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < PX; ++i)
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
                 const float u = rbf(acc[i][1][e]);                  // up_proj output (bf16)
                 o[e] = f2bf(sg * u);
             }
-            *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
+            bf16* dst = a.okb ? a.out + ((long)(col >> 5) * a.okb + row) * 32 + (col & 31) : a.out + (long)row * a.ldo + col;
+            *reinterpret_cast<bf16x4*>(dst) = o;
         }
     }
 }

@@ -72,8 +72,10 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));
-                if constexpr (XN_SC1) store16_sc1(a.xn, ((long)row * a.ldx + c * 8) * 2, __builtin_bit_cast(u32x4_t, o));
-                else *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+                // xkb: xn k-blocked [H/32][xkb rows][32] for the mid-M GEMM (gemm_wl.hip), else row-major
+                const long xo = a.xkb ? ((long)(c >> 2) * a.xkb + row) * 32 + (c & 3) * 8 : (long)row * a.ldx + c * 8;
+                if constexpr (XN_SC1) store16_sc1(a.xn, xo * 2, __builtin_bit_cast(u32x4_t, o));
+                else *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
             }
             return;
         }
@@ -87,7 +89,8 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(bf2f(hh[e]) * rstd));
-        *reinterpret_cast<bf16x8*>(a.xn + (long)row * a.ldx + c * 8) = o;
+        const long xo = a.xkb ? ((long)(c >> 2) * a.xkb + row) * 32 + (c & 3) * 8 : (long)row * a.ldx + c * 8;
+        *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
     }
 }
 

@@ -701,16 +701,47 @@ def test_row_blocks_above_256_stay_bit_identical():
     g = torch.Generator().manual_seed(41)
     pre = (torch.randn(B, 20, H, generator=g) * 0.3).bfloat16().cuda()
     x = (torch.randn(B, tf, H, generator=g) * 0.3).bfloat16().cuda()
-    solo = []
+    solo, solo_act = [], []
     for b in range(B):
         st = rt.open_stream("default_sink", 128, 8)
         rt.lm_step([st], pre[b:b + 1])
         solo.append(rt.lm_step([st], x[b:b + 1]).clone())
+        solo_act.append(rt.debug_tap("act", 1, tf).clone())   # SwiGLU activation of the last layer, [36][inter]
+        st.close()
+    # act_kb = 2 (default): the mid-M kernels pass the normed gate/up input and the SwiGLU activation k-blocked; 1: the
+    # activation only; 0: row-major.  Same bits, and the parity tap un-blocks the activation.
+    for act_kb in (2, 1, 0):
+        rt.set_tuning("act_kb", act_kb)
+        sts = [rt.open_stream("default_sink", 128, 8) for _ in range(B)]
+        rt.lm_step(sts, pre)
+        batched = rt.lm_step(sts, x)                   # 288 rows in one step
+        assert torch.isfinite(batched).all() and torch.equal(batched, torch.cat(solo)), act_kb
+        assert torch.equal(rt.debug_tap("act", B, tf), torch.cat(solo_act)), act_kb
+        for st in sts:
+            st.close()
+    rt.set_tuning("act_kb", 2)
+    rt.close()
+
+
+def test_two_row_chunks_of_the_mid_m_kernel_stay_bit_identical():
+    """12 streams x 36 tokens = 432 rows: two even row chunks (224 + 208), both in the mid-M kernel, k-blocked activation with
+    the chunk offset inside the panels.  Equal to the twelve solo steps bit for bit."""
+    cfg = _bench_width_cfg(1)
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    rt = _rt(cfg, w, max_step_tokens=448, max_vit_frames=1, max_positions=4096)
+    H, tf, B = cfg.lm.hidden_size, cfg.frame_num_tokens, 12
+    g = torch.Generator().manual_seed(43)
+    x = (torch.randn(B, tf, H, generator=g) * 0.3).bfloat16().cuda()
+    solo, solo_act = [], []
+    for b in range(B):
+        st = rt.open_stream("default_sink", 128, 8)
+        solo.append(rt.lm_step([st], x[b:b + 1]).clone())
+        solo_act.append(rt.debug_tap("act", 1, tf).clone())
         st.close()
     sts = [rt.open_stream("default_sink", 128, 8) for _ in range(B)]
-    rt.lm_step(sts, pre)
-    batched = rt.lm_step(sts, x)                       # 288 rows in one step
+    batched = rt.lm_step(sts, x)
     assert torch.isfinite(batched).all() and torch.equal(batched, torch.cat(solo))
+    assert torch.equal(rt.debug_tap("act", B, tf), torch.cat(solo_act))
     for st in sts:
         st.close()
     rt.close()
