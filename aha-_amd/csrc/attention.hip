@@ -700,17 +700,32 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
-    float M = -INFINITY;
-    for (int s = 0; s < ns; ++s) M = fmaxf(M, a.part_ml[((base + s) * Rpad + r) * 2]);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const long prow = (base + s) * Rpad + r;
-        const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima live in the base-2 domain
-        L += w * a.part_ml[prow * 2 + 1];
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0), p1 = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+    // every load of every split is independent of the running maximum: issue them all at once (at most 16 splits, the
+    // launcher's cap), then reduce in split order - one memory round trip instead of two dependent ones per split
+    float m_[16], l_[16];
+    f32x4 p0[16], p1[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[e] += w * p0[e]; acc[4 + e] += w * p1[e]; }
-    }
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) {
+            const long prow = (base + s) * Rpad + r;
+            m_[s] = a.part_ml[prow * 2];
+            l_[s] = a.part_ml[prow * 2 + 1];
+            p0[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0);
+            p1[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+        }
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) M = fmaxf(M, m_[s]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) {
+            const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima live in the base-2 domain
+            L += w * l_[s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += w * p0[s][e]; acc[4 + e] += w * p1[s][e]; }
+        }
     const int g = r / a.T, t = r % a.T;
     bf16x8 ov;
 #pragma unroll
@@ -726,15 +741,28 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
+    // all loads first (independent of the maximum; at most 16 splits), then the reduction in split order
+    float m_[16], l_[16], p_[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) {
+            const long prow = (base + s) * Rpad + r;
+            m_[s] = a.part_ml[prow * 2];
+            l_[s] = a.part_ml[prow * 2 + 1];
+            p_[s] = a.part_o[prow * D + d];
+        }
     float M = -INFINITY;
-    for (int s = 0; s < ns; ++s) M = fmaxf(M, a.part_ml[((base + s) * Rpad + r) * 2]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) M = fmaxf(M, m_[s]);
     float acc = 0.f, L = 0.f;
-    for (int s = 0; s < ns; ++s) {
-        const long prow = (base + s) * Rpad + r;
-        const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(a.part_ml[prow * 2] - M);    // running maxima are kept in the base-2 domain
-        L += w * a.part_ml[prow * 2 + 1];
-        acc += w * a.part_o[prow * D + d];
-    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s < ns) {
+            const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima are kept in the base-2 domain
+            L += w * l_[s];
+            acc += w * p_[s];
+        }
     const int g = r / a.T, t = r % a.T;
     if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(L > 0.f ? acc / L : 0.f);
 }
@@ -799,6 +827,7 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
 // channels zero-padded on chip (so400m: 72 -> 128).
 extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
     if (!sd && a_->n_splits != 1) return hipErrorInvalidValue;
+    if (a_->n_splits < 1 || a_->n_splits > 16) return hipErrorInvalidValue;      // the combine kernels hold one value per split in registers
     if (head_dim < 8 || head_dim > 128 || (head_dim & 7)) return hipErrorInvalidValue;
     AttnArgs a = *a_;
     a.hd = head_dim;
