@@ -296,6 +296,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "use_wl") c->use_wl = value;
     else if (k == "dev_xkb") c->dev_xkb = value;
     else if (k == "act_kb") c->act_kb = value;
+    else if (k == "wl_bal") aha_gemm_wl_set_balanced(value);
     else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
     else if (k == "layer_count") c->layer_count = value;
     else if (k == "fuse_static") c->fuse_static = value;

@@ -149,6 +149,120 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gate/up + SwiGLU at 18 row tiles (M = 273..288: BASELINE configs[3]'s 8 streams x 36 tokens, and the 8-frame static batch):
+// the same staging and the same per-element arithmetic as gemm_wl_kernel<18, 5, EPI_SWIGLU>, with the 90 (row tile, gate/up
+// pair) units of a k-step dealt to the ten waves by where the waves SIT.  A workgroup's waves go round the four SIMDs in
+// launch order (MI355X_MICROARCH.md, LDS section), so waves {0,4,8} and {1,5,9} share a SIMD three at a time and {2,6}, {3,7}
+// two at a time: with nine units per wave the three-wave SIMDs carry 54 MFMAs per k-step and set the pace (the round-2
+// ablation: MFMA-only time 60 of 90 us).  Here the three-wave SIMDs' waves take 7 units each (7 rows x 1 pair: 42 MFMAs per
+// SIMD) and the two-wave SIMDs' waves 12 (6 rows x 2 pairs, or 4 rows x 3 pairs: 48 per SIMD); fragment reads drop from 110
+// to 94 per k-step.  Every output element still sums its k-steps in the same order in one accumulator: bit-identical.
+//   wave 2: rows  0-5  pairs 0-1     wave 3: rows 6-11 pairs 0-1     wave 6: rows 12-17 pairs 0-1     wave 7: rows 0-3 pairs 2-4
+//   waves 0,4,8: rows 4-10 of pair 2,3,4         waves 1,5,9: rows 11-17 of pair 2,3,4
+// ---------------------------------------------------------------------------------------------
+template <int NR, int NP>
+static __device__ __forceinline__ void wl_bal_body(const GemmWsArgs& a, bf16* lds, const int row0, const int pair0, const int lane, const int wave) {
+    constexpr int MT = 18, WN = 5, STAGES = 5, NW = 10, NTB = 10;
+    constexpr int NB = MT + NTB, PX = 2, P = PX + 1, STAGE = NB * 512;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int KS = a.KS, ksx_last = a.Kx / 32 - 1;                  // S = 1: the whole K range
+    const bf16* xsrc[PX];
+    int xblk[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        xblk[i] = min(wave + i * NW, MT - 1);
+        const int row = min(xblk[i] * 16 + (lane >> 2), a.M - 1);
+        const int c = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+        xsrc[i] = a.X + (long)row * (a.xkb ? 32 : a.ldx) + c * 8;
+    }
+    const long xkstride = a.xkb ? (long)a.xkb * 32 : 32;
+    const bf16* wsrc = reinterpret_cast<const bf16*>(a.Wp + ((long)min((int)blockIdx.x * NTB + wave, a.n_tiles - 1) * KS) * 64 + lane);
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](int kt, int stage) {
+        const int ks = min(kt, KS - 1);
+        const long xk = min(ks, ksx_last) * xkstride;
+        bf16* sa = lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < PX; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xk), (lptr_t)(sa + xblk[i] * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (long)ks * 512), (lptr_t)(sa + (MT + wave) * 512), 16, 0, 2);
+    };
+    f32x4 acc[NR][NP][2];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { acc[i][p][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][p][1] = acc[i][p][0]; }
+    const int xslot = (r16 * 4 + (q ^ ((4 - (r16 >> 2)) & 3))) * 8;
+    const int xoff = row0 * 512 + xslot, woff = (MT + pair0 * 2) * 512 + lane * 8;
+    bf16x8 xf[NR], wf[NP][2];
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) dma(s, s);
+    int st_cur = 0, st_new = STAGES - 1;
+    for (int kt = 0; kt < KS; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");
+        __builtin_amdgcn_s_barrier();
+        dma(kt + STAGES - 1, st_new);
+        const bf16* sa = lds + st_cur * STAGE;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            wf[p][0] = *reinterpret_cast<const bf16x8*>(sa + woff + p * 1024);
+            wf[p][1] = *reinterpret_cast<const bf16x8*>(sa + woff + p * 1024 + 512);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + xoff + i * 512);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                acc[i][p][0] = mfma16(wf[p][0], xf[i], acc[i][p][0]);
+                acc[i][p][1] = mfma16(wf[p][1], xf[i], acc[i][p][1]);
+            }
+        st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
+        st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue: SwiGLU of (gate tile, up tile) pairs, as gemm_wl_kernel
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int tile0 = (int)blockIdx.x * NTB + (pair0 + p) * 2;
+        if (tile0 >= a.n_tiles) continue;
+        const int col = (tile0 / 2) * 16 + q * 4;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = (row0 + i) * 16 + r16;
+            if (row >= a.M || col >= a.N) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g = rbf(acc[i][p][0][e]);
+                const float sg = rbf(g / (1.0f + __expf(-g)));
+                const float u = rbf(acc[i][p][1][e]);
+                o[e] = f2bf(sg * u);
+            }
+            bf16* dst = a.okb ? a.out + ((long)(col >> 5) * a.okb + row) * 32 + (col & 31) : a.out + (long)row * a.ldo + col;
+            *reinterpret_cast<bf16x4*>(dst) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(640) void gemm_wl_bal18_kernel(GemmWsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wl_smem[];
+    bf16* lds = reinterpret_cast<bf16*>(wl_smem);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {                                                     // wave-uniform; every path runs the same barriers
+        case 2: wl_bal_body<6, 2>(a, lds, 0, 0, lane, wave); break;
+        case 3: wl_bal_body<6, 2>(a, lds, 6, 0, lane, wave); break;
+        case 6: wl_bal_body<6, 2>(a, lds, 12, 0, lane, wave); break;
+        case 7: wl_bal_body<4, 3>(a, lds, 0, 2, lane, wave); break;
+        default: wl_bal_body<7, 1>(a, lds, (wave & 1) ? 11 : 4, 2 + (wave >> 2), lane, wave); break;   // waves 0,1,4,5,8,9
+    }
+}
+static int g_wl_bal = 1;         // tuning "wl_bal": SIMD-balanced unit deal of the 18-row-tile gate/up kernel (0: nine units per wave)
+extern "C" void aha_gemm_wl_set_balanced(int on) { g_wl_bal = on; }
+
 template <int MT, int WN, int EPI>
 static hipError_t launch_wl(const GemmWsArgs& a, hipStream_t st) {
     constexpr int NB = MT + 2 * WN;
@@ -185,6 +299,17 @@ extern "C" int aha_gemm_wl_supports(const GemmWsArgs* a, int epi) {
 
 extern "C" hipError_t aha_gemm_wl(const GemmWsArgs* a, int epi, hipStream_t st) {
     if (!aha_gemm_wl_supports(a, epi)) return hipErrorInvalidValue;
+    if (epi == EPI_SWIGLU && g_wl_bal && ceil_div(a->M, 16) == 18 && a->S == 1) {
+        constexpr int LDS = 5 * 28 * 1024;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_wl_bal18_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_wl_bal18_kernel, dim3(ceil_div(a->n_tiles, 10)), dim3(640), LDS, st, *a);
+        return hipGetLastError();
+    }
     if (epi == EPI_SWIGLU) return dispatch_wl<5, EPI_SWIGLU>(*a, st);
     return dispatch_wl<4, EPI_PARTIAL>(*a, st);
 }

@@ -50,12 +50,12 @@ def step_ms(sts, x, n=30):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for B in (1, 2, 8):
+for B in (1, 8):
     sts, x = fill(B)
-    for use_wl in (0, 1, 2, 0, 2):
-        rt.set_tuning("act_kb", use_wl)
+    for use_wl in (0, 1, 0, 1):
+        rt.set_tuning("wl_bal", use_wl)
         k = kinds(sts, x)
-        print(f"B={B} act_kb={use_wl}: step {step_ms(sts, x):.3f} ms; us per launch group: " + "  ".join(f"{a} {b:.1f}" for a, b in k.items()), flush=True)
+        print(f"B={B} wl_bal={use_wl}: step {step_ms(sts, x):.3f} ms; us per launch group: " + "  ".join(f"{a} {b:.1f}" for a, b in k.items()), flush=True)
     rt.set_tuning("use_wl", 1)
     for nw in ():
         rt.set_tuning("attn_lm", nw)
