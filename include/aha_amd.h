@@ -107,6 +107,9 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *   "attn_lm"         LM attention kernel for frame-sized steps: 0 attn_fwd_kernel always, 1 auto (default), 2 attn_lm_kernel always
  *   "use_wl"          1 (default): row chunks above 128 use the mid-M GEMM kernel (both operands staged through LDS); 0: never.
  *                     Bit-identical either way
+ *   "act_kb"          2 (default): between mid-M kernels the normed gate/up input and the SwiGLU activation travel k-blocked
+ *                     ([K/32][M][32]); 1: the activation only; 0: row-major.  "wl_bal" 1 (default): the 18-row-tile gate/up kernel
+ *                     deals its MFMA units by SIMD occupancy; 0: nine units per wave.  Bit-identical either way
  *   "tile_epi"        1 (default): the LDS-DMA tiled GEMMs stage the finished tile in LDS and store full 128-byte rows; 0: direct
  *                     accumulator-layout stores.  Bit-identical either way
  *   "layer_first" / "layer_count"  run decoder layers [first, first+count) only (0 = all): teacher-forced per-layer parity */

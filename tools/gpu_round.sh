@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU session: parity tests, smoke, default bench (+CPU baseline), kernel trace, PMC passes, ingest timing.
+# One GPU session: parity tests, smoke, default bench (+CPU baseline), kernel trace, ingest timing (PMC passes: tools/pmc_round.sh, a call of its own).
 # Summaries land in gpurun_out/round/ ; copy the ones to be judged into profiles/ (tracked).
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; rm -rf $O; mkdir -p $O
@@ -10,11 +10,7 @@ timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench.err; echo 
 timeout -k 10 120 python tools/diag/ingest_time.py > $O/ingest_time.txt 2>&1; echo "INGEST rc=$?"; grep "us/frame" $O/ingest_time.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_trace.json 2> $O/bench_trace.err; echo "TRACE rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline > $O/bench_fetch.json 2> $O/bench_fetch.err; echo "PMC_FETCH rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 $R/bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline > $O/bench_write.json 2> $O/bench_write.err; echo "PMC_WRITE rc=$?"
 cd $R
 cp $(find $O/prof_trace -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-python tools/pmc_summary.py $O/prof_fetch $O/prof_write $O/pmc_hbm_traffic.json
-rm -rf $O/prof_fetch $O/prof_write                     # raw counter dumps are large; the summary is what is kept
 find $O/prof_trace -name "*kernel_trace.csv" -size +30M -delete
 head -12 $O/bench_kernel_stats.csv | cut -c1-150
