@@ -599,7 +599,7 @@ def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, 
     M = B2 * tf
     flops = 2.0 * M * (2 * cfg.lm.intermediate_size) * cfg.lm.hidden_size
     tf_s = flops / ((g_ms / g_n) * 1e-3) / 1e12 if g_n else None
-    rl = roofline_hbm("gemm_wl_kernel<18,5,SWIGLU> (gate/up + SwiGLU at M = 288 rows)", g_ms, g_n, g_by, "gemm_wl_kernel<18, 5,")
+    rl = roofline_hbm("gemm_wl_bal18_kernel (gate/up + SwiGLU at M = 288 rows)", g_ms, g_n, g_by, "gemm_wl_bal18_kernel")
     rl.update({"mfma_achieved_TFLOPs": tf_s, "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS, "mfma_frac": tf_s / MFMA_PEAK_TFLOPS if tf_s else None,
                "flops_per_launch": flops, "note": "arithmetic intensity ~288 flop/B sits on the ridge (312): both fractions are reported"})
     out = {"workload": f"{B2} streams/GPU, SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step (M = {M} rows per LM step)",
