@@ -1141,7 +1141,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                 qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
                 const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
                 if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
-                HIPCHK(c, aha_qkv_finish_attn_static(&qa, c->sd_dev, M, c->attn_out, QD, 1.0f / sqrtf((float)Dh), st));
+                HIPCHK(c, aha_qkv_finish_attn_static(&qa, c->sd_dev, M, T, c->attn_out, QD, 1.0f / sqrtf((float)Dh), st));
                 if (t_attn) {
                     double by = 0;
                     for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;

@@ -161,6 +161,7 @@ struct StaticAttnArgs {
     QkvFinishArgs qa;
     bf16* out; int ldo;              // attention output rows [M][Hq*D]
     float scale; int G;
+    int T;                           // tokens per stream of the step (= the descriptor's T)
 };
 
 template <int D>
@@ -172,25 +173,9 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
     __shared__ float ps[GMAX * LMAX];
     const QkvFinishArgs& a = p.qa;
     const int row = blockIdx.x, hk = blockIdx.y, tid = threadIdx.x, G = p.G;
-    const int T = sdp->T, b = row / T, t = row % T;
-    const StreamStep ss = sdp->s[b];
-    const int Lk = min(ss.len_after, LMAX);
-    int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
-    // keys 0 .. nvis-1 are visible to this row: all of them under the sdpa-style rule; j <= causal_off + t under flash-attn-2's
-    // bottom-right alignment (causal_off = L - T: the first T - L rows of a frame then see nothing and give 0)
-    const int nvis = max(0, min(Lk, ss.causal_off > (1 << 28) ? Lk : ss.causal_off + t + 1));
-
-    // ---- the frozen prefix of this KV head -> LDS (issued first: independent of the slab reduce below)
-    {
-        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
-        for (int c = tid; c < Lk * (D / 8); c += 256) {
-            const int j = c / (D / 8), ch = c % (D / 8);
-            const long so = lo + (long)phys_slot(ss, j) * D + ch * 8;
-            *reinterpret_cast<bf16x8*>(&Ksh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.k_base + so);
-            *reinterpret_cast<bf16x8*>(&Vsh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.v_base + so);
-        }
-    }
-    // ---- rotated queries of the G heads (qkv_finish_kernel's arithmetic)
+    // Memory round trips are this kernel's time, so they are issued in dependency order, not reading order: (1) this thread's
+    // slab loads need only the row; (2) the step descriptor (T comes as an argument: one dependent load less); (3) the prefix
+    // K/V, whose addresses come from the descriptor; RoPE (needs the position) runs last on the values already in registers.
     auto fetch4 = [&](int col, float (&o)[4]) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* pp = a.partial + (long)row * a.ldp + col;
@@ -207,11 +192,43 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rbf(acc[e] + bf2f(bv[e]));
     };
+    // first (for head_dim 128 and G <= 8: only) item of this thread: 4 rotation pairs of one query head
+    const bool first = tid < G * IPH;
+    float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (first) {
+        const int col = (hk * G + tid / IPH) * D + (tid % IPH) * 4;
+        fetch4(col, f1);
+        fetch4(col + HALF, f2);
+    }
+    const int T = p.T, b = row / T, t = row % T;
+    const StreamStep ss = sdp->s[b];
+    const int Lk = min(ss.len_after, LMAX);
+    int pos = ss.pos_base + t; if (pos > a.n_pos - 1) pos = a.n_pos - 1;
+    // keys 0 .. nvis-1 are visible to this row: all of them under the sdpa-style rule; j <= causal_off + t under flash-attn-2's
+    // bottom-right alignment (causal_off = L - T: the first T - L rows of a frame then see nothing and give 0)
+    const int nvis = max(0, min(Lk, ss.causal_off > (1 << 28) ? Lk : ss.causal_off + t + 1));
+
+    // ---- the frozen prefix of this KV head -> LDS
+    {
+        const long lo = ((long)a.layer * a.Hkv + hk) * ss.cap * D;
+        for (int c = tid; c < Lk * (D / 8); c += 256) {
+            const int j = c / (D / 8), ch = c % (D / 8);
+            const long so = lo + (long)phys_slot(ss, j) * D + ch * 8;
+            *reinterpret_cast<bf16x8*>(&Ksh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.k_base + so);
+            *reinterpret_cast<bf16x8*>(&Vsh[j * KST + ch * 8]) = *reinterpret_cast<const bf16x8*>(ss.v_base + so);
+        }
+    }
+    // ---- rotated queries of the G heads (qkv_finish_kernel's arithmetic)
     for (int it = tid; it < G * IPH; it += 256) {
         const int g = it / IPH, dd = (it % IPH) * 4, col = (hk * G + g) * D + dd;
         float x1[4], x2[4];
-        fetch4(col, x1);
-        fetch4(col + HALF, x2);
+        if (it == tid && first) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x1[e] = f1[e]; x2[e] = f2[e]; }
+        } else {
+            fetch4(col, x1);
+            fetch4(col + HALF, x2);
+        }
         const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + dd), s1 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + dd);
         const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(a.rope_cos + (long)pos * D + dd + HALF), s2 = *reinterpret_cast<const bf16x4*>(a.rope_sin + (long)pos * D + dd + HALF);
 #pragma unroll
@@ -243,7 +260,13 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
         if (i < G * Lk) {
             const int gi = i / Lk;
             float m = -INFINITY;
-            for (int j = 0; j < nvis; ++j) m = fmaxf(m, ps[gi * LMAX + j]);
+            for (int j = 0; j < nvis; j += 8) {              // eight independent LDS reads in flight (the serial loop cost ~1 us of latency)
+                float v8[8];
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8) v8[u8] = j + u8 < nvis ? ps[gi * LMAX + j + u8] : -INFINITY;
+#pragma unroll
+                for (int u8 = 0; u8 < 8; ++u8) m = fmaxf(m, v8[u8]);
+            }
             pj[u] = (i % Lk) < nvis ? __builtin_amdgcn_exp2f(__builtin_fmaf(ps[gi * LMAX + i % Lk], c2, -m * c2)) : 0.f;
         }
     }
@@ -258,7 +281,8 @@ __global__ __launch_bounds__(256) void qkv_finish_attn_static_kernel(StaticAttnA
     for (int i = tid; i < G * (D / 4); i += 256) {
         const int g = i / (D / 4), dd = (i % (D / 4)) * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
-        for (int j = 0; j < Lk; ++j) {
+#pragma unroll 4
+        for (int j = 0; j < Lk; ++j) {                      // loads of four keys in flight; the sums stay in j order
             const float pv = ps[g * LMAX + j];
             l += pv;
             const float pb = rbf(pv);
@@ -658,9 +682,9 @@ hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M,
     return hipGetLastError();
 }
 // G <= 8 query heads per KV head, every stream's frozen prefix <= 64 keys (the caller checks both)
-hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, bf16* out, int ldo, float scale, hipStream_t st) {
+hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, int T, bf16* out, int ldo, float scale, hipStream_t st) {
     StaticAttnArgs p;
-    p.qa = *a; p.out = out; p.ldo = ldo; p.scale = scale; p.G = a->Hq / a->Hkv;
+    p.qa = *a; p.out = out; p.ldo = ldo; p.scale = scale; p.G = a->Hq / a->Hkv; p.T = T;
     if (p.G > 8) return hipErrorInvalidValue;
     if (a->D == 64) hipLaunchKernelGGL((qkv_finish_attn_static_kernel<64>), dim3(M, a->Hkv), dim3(256), 0, st, p, sd_dev);
     else if (a->D == 128) hipLaunchKernelGGL((qkv_finish_attn_static_kernel<128>), dim3(M, a->Hkv), dim3(256), 0, st, p, sd_dev);
