@@ -232,6 +232,57 @@ static __device__ __forceinline__ bool tile_epilogue_wide_ok(const GemmTileArgs&
     return g.wide_epi && !(g.N & 7) && !(g.ldc & 7) && (!g.residual || !(g.ldr & 7)) && (!g.rowadd || !(g.ldra & 7));
 }
 
+// The same epilogue with ONE staging image for the whole workgroup (BM x BN bf16, row stride BN + 8): for wave tiles narrower
+// than 128 bytes (the 288 x 128 tile's waves own 144 x 32) the per-wave image would store half lines.  All waves write
+// their part, one barrier, then every wave-instruction moves 1 KiB = whole BN-wide rows.  Same rounding points.
+template <int BM, int BN, int WI, int WJ, int NT>
+static __device__ __forceinline__ void tile_epilogue_lds_wg(const GemmTileArgs& g, f32x4 (&acc)[WI][WJ], bf16* stg, const int m0, const int n0,
+                                                            const int mw, const int nw, const int tid) {
+    constexpr int ST = BN + 8, CPR = BN / 8;                         // staging row stride in elements; 16-B chunks per row
+    const int lane = tid & 63, q = lane >> 4, r16 = lane & 15;
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int n = min(n0 + nw + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));            // Linear output (bf16)
+                if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
+                else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
+                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
+                o[e] = f2bf(x);
+            }
+            *reinterpret_cast<bf16x4*>(&stg[(mw + i * 16 + r16) * ST + nw + j * 16 + q * 4]) = o;
+        }
+    __syncthreads();
+    static_assert((BM * CPR) % NT == 0, "tile must split into whole rounds of 16-byte stores");
+#pragma unroll
+    for (int it = 0; it < (BM * CPR) / NT; ++it) {
+        const int idx = it * NT + tid, row = idx / CPR, ch = idx % CPR;
+        const int m = m0 + row, n = n0 + ch * 8;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(&stg[row * ST + ch * 8]);
+        const int mc = min(m, g.M - 1), nc = min(n, g.N - 8);
+        bf16x8 rv, pv;
+        if (g.residual) rv = *reinterpret_cast<const bf16x8*>(g.residual + (long)mc * g.ldr + nc);
+        if (g.rowadd) pv = *reinterpret_cast<const bf16x8*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + nc);
+        if (g.residual)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(rv[e]) + bf2f(v[e])));
+        if (g.rowadd)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(v[e]) + bf2f(pv[e])));
+        if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS-DMA family (K % 64 == 0): block tile BM x BN = (WAVES_M*16*WI) x (WAVES_N*16*WJ), one wave per
 // (16*WI) x (16*WJ) sub-tile, STAGES stages of (BM+BN) 128-byte rows filled by global_load_lds_dwordx4
@@ -440,12 +491,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_tile_dma_kernel(G
 // four 256-byte bank rows and get four different 16-byte slots in each - conflict-free.  Same k order: bit-identical.
 // ---------------------------------------------------------------------------------------------
 template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_kernel(GemmTileArgs g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void gemm_tile_dma32_kernel(GemmTileArgs g) {
     constexpr int BK = 32;
     constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ, NT = 64 * WAVES_M * WAVES_N;
     constexpr int ROWS = BM + BN, STAGE = ROWS * BK;
-    constexpr int P = ROWS * 4 / NT;                                // 16-B DMA pieces per thread per stage
-    static_assert(ROWS * 4 % NT == 0, "stage image must split evenly over the threads");
+    constexpr int NPIECE = ROWS * 4 / 64, NWV = NT / 64;           // 1-KiB wave-pieces per stage; waves
+    constexpr int P = (NPIECE + NWV - 1) / NWV;                     // DMA wave-instructions per wave per stage (surplus ones re-load the last piece:
+                                                                    // same bytes to the same place, so every wave's vmcnt counts stay equal)
+    static_assert(ROWS % 16 == 0, "stage image must split into whole 1-KiB pieces");
     static_assert((STAGES - 2) * P <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
     bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
@@ -471,12 +524,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
 #pragma unroll
         for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const bf16* src[P];
+    // a piece (16 rows) lies entirely in A or entirely in W: wave-uniform base + a 32-bit per-lane byte offset (one VGPR per piece;
+    // check_tile_args keeps M*lda and N*ldw below 2^31 elements)
+    const char* pbase[P];
+    unsigned poff[P];
+    int pdst[P];                                                    // element offset of this wave's piece inside a stage (wave-uniform)
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const int c = i * NT + tid, row = c >> 2, ch = (c & 3) ^ ((row >> 2) & 3);
-        src[i] = row < BM ? g.A + min(m0 + row, g.M - 1) * g.lda + ch * 8
-                          : g.W + min(n0 + row - BM, g.N - 1) * g.ldw + ch * 8;
+        const int wp = min(i * NWV + __builtin_amdgcn_readfirstlane(wave), NPIECE - 1);
+        const int c = wp * 64 + lane, row = c >> 2, ch = (c & 3) ^ ((row >> 2) & 3);
+        const bool isA = wp * 16 < BM;                              // BM % 16 == 0
+        pbase[i] = reinterpret_cast<const char*>(isA ? g.A : g.W);
+        poff[i] = isA ? ((unsigned)min(m0 + row, g.M - 1) * (unsigned)g.lda + ch * 8) * 2u
+                      : ((unsigned)min(n0 + row - BM, g.N - 1) * (unsigned)g.ldw + ch * 8) * 2u;
+        pdst[i] = wp * 512;
     }
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -486,7 +547,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
         const int k0 = min(s, nk - 1) * BK;
 #pragma unroll
         for (int i = 0; i < P; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + k0), (lptr_t)(lds + s * STAGE + (i * NT + wave * 64) * 8), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pbase[i] + k0 * 2 + poff[i]), (lptr_t)(lds + s * STAGE + pdst[i]), 16, 0, 0);
     }
     int st_cur = 0, st_new = STAGES - 1;
     for (int kt = 0; kt < nk; ++kt) {
@@ -516,7 +577,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
                 const int n = i * WJ + j + 1;
                 if (n % PER == 0 && n / PER <= P) {
                     const int pc = n / PER - 1;
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src[pc] + k0), (lptr_t)(sn + (pc * NT + wave * 64) * 8), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(pbase[pc] + k0 * 2 + poff[pc]), (lptr_t)(sn + pdst[pc]), 16, 0, 0);
                 }
             }
         __builtin_amdgcn_sched_group_barrier(0x100, WI + WJ, 0);
@@ -533,7 +594,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_tile_dma32_ker
 
     if (tile_epilogue_wide_ok(g)) {                                // uniform
         __builtin_amdgcn_s_barrier();
-        tile_epilogue_lds<WI, WJ>(g, acc, lds + wave * (16 * WI * (16 * WJ + 8)), m0 + wm * (16 * WI), n0 + wn * (16 * WJ), lane);
+        if constexpr (WJ * 16 >= 64)
+            tile_epilogue_lds<WI, WJ>(g, acc, lds + wave * (16 * WI * (16 * WJ + 8)), m0 + wm * (16 * WI), n0 + wn * (16 * WJ), lane);
+        else
+            tile_epilogue_lds_wg<BM, BN, WI, WJ, NT>(g, acc, lds, m0, n0, wm * (16 * WI), wn * (16 * WJ), tid);
         return;
     }
     const bf16x4 z4 = {0, 0, 0, 0};
@@ -579,7 +643,7 @@ template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
 static hipError_t launch_dma32(const GemmTileArgs* g, hipStream_t st) {
     constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
     constexpr int lds_bytes = STAGES * (BM + BN) * 32 * 2;
-    static_assert(lds_bytes >= WAVES_M * WAVES_N * 16 * WI * (16 * WJ + 8) * 2, "stage ring must hold the epilogue staging image");
+    static_assert(lds_bytes >= (WJ * 16 >= 64 ? WAVES_M * WAVES_N * 16 * WI * (16 * WJ + 8) : BM * (BN + 8)) * 2, "stage ring must hold the epilogue staging image");
     static bool attr_set = false;
     auto kern = gemm_tile_dma32_kernel<WI, WJ, WAVES_M, WAVES_N, STAGES>;
     if (!attr_set) {
@@ -819,6 +883,7 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 7: return launch_256(g, st);                        // 256x256, 8 waves, 128 KB, half-tile refills
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
         case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
+        case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
         default: return hipErrorInvalidValue;
     }
 }
@@ -852,7 +917,12 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
             v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
         }
         if (v == 1) {
-            if (g->K < 2048 && nblk_l >= 400) v = 8;     // 32-deep stages, two workgroups per CU: +7-10 % on the K = 1024 GEMMs
+            // 576-patch towers: M is a multiple of 288.  The 288x128 tile is ~10 % slower per flop than 256x128 (11 fragment
+            // reads per 18 MFMAs, 128 VGPRs) and wins exactly where it turns "one round of the chip's 512 resident workgroups
+            // plus a stub" into one round: out-proj at 32 frames (576 -> 512 tiles: 63 -> 52 us), fc1 at 8 frames (65 -> 53 us).
+            const int t288 = (g->M % 288 == 0) ? (g->M / 288) * ceil_div(g->N, 128) : 0;
+            if (g->K < 2048 && t288 > 400 && t288 <= 512 && nblk_l > 512) v = 11;
+            else if (g->K < 2048 && nblk_l >= 400) v = 8;     // 32-deep stages, two workgroups per CU: +7-10 % on the K = 1024 GEMMs
             else v = ((util >= 0.6f || (g->K >= 2048 && util >= 0.5f)) && (g->N > 1024 || g->K > 1024)) ? 2 : 5;
         }
         return launch_dma_variant(v, g, st);

@@ -19,12 +19,12 @@ def bench(M, N, K, variant, n=12):
     for i in range(n): lib.aha_dev_gemm_tile(A[i % 2].data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, variant, st)
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-names = {1: "auto", 2: "256x128x64 ilv", 3: "128x128x64 4st", 5: "64x64", 8: "256x128x32 2/CU", 7: "256x256"}
-for frames in (32, 128):
+names = {1: "auto", 2: "256x128x64 ilv", 3: "128x128x64 4st", 5: "64x64", 8: "256x128x32 2/CU", 7: "256x256", 11: "288x128x32 2/CU"}
+for frames in (8, 32, 64, 128):
     M = frames * 576
     for name, N, K in (("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)):
         row = []
-        for v in (1, 2, 3, 8, 7):
+        for v in (1, 2, 8, 11):
             t = bench(M, N, K, v)
             row.append(f"{names[v]} {t:7.1f} us ({2.0 * M * N * K / t / 1e6:5.0f} TF)")
         print(f"{frames:3d} frames {name}: " + " | ".join(row), flush=True)
