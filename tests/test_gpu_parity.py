@@ -307,7 +307,7 @@ def test_7b_wide_two_layer_parity():
 def bench_rt():
     cfg = preset("bench")
     w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
-    rt = _rt(cfg, w, max_step_tokens=160, max_vit_frames=8)
+    rt = _rt(cfg, w, max_step_tokens=160, max_vit_frames=32)
     del w
     torch.cuda.empty_cache()
     yield cfg, rt
@@ -427,6 +427,19 @@ def test_full_size_batched_streams_and_vit_batches(bench_rt):
     st.close()
     for s in solo + both:
         s.close()
+
+
+def test_vit_batch_of_32_frames_equals_batches_of_4_and_8(bench_rt):
+    """The bench's batch size: 32 frames (18,432 patch rows) pick other tile variants than small batches do - the 288x128 tile on
+    the out-projection (512 tiles = one round of the chip), 256x128 elsewhere; at 8 frames fc1 takes the 288-row tile.  Every
+    frame's embedding must not depend on the batch it was encoded in (bit-exact)."""
+    cfg, rt = bench_rt
+    fr = make_frames(32, cfg.vision.image_size, seed=9).cuda()
+    e32 = rt.visual_embed(fr).clone()
+    e8 = torch.cat([rt.visual_embed(fr[i:i + 8]).clone() for i in range(0, 32, 8)], 0)
+    e4 = torch.cat([rt.visual_embed(fr[i:i + 4]).clone() for i in range(0, 32, 4)], 0)
+    assert torch.isfinite(e32.float()).all()
+    assert torch.equal(e32, e8) and torch.equal(e32, e4)
 
 
 def test_reference_faithful_vision_shapes_head_dim_72():
