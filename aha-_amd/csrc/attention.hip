@@ -804,8 +804,9 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
         // dense (vision tower): one query tile per wave while the grid is small (single-frame latency), more tiles per
         // wave (less K/V staging per flop) once it fills the chip several times over
         // Measured on 32 frames (4608 x 10 key blocks): 1 / 2 / 3 tiles per wave give the same tower time within noise
-        // (20.2 / 20.6 / 20.2 ms): the kernel is bound by instruction issue (VALU softmax + exp + LDS fragment reads +
-        // MFMA add up to the measured ~108 us with little overlap), not by K/V staging.  Default: one tile per wave, the
+        // (20.2 / 20.6 / 20.2 ms), so K/V staging is not what bounds it; halving the softmax's FMA / add instruction count with
+        // packed fp32 ops and skipping idle rescales did not move it either (profiles/r02_vit_batch.txt): the per-block chain
+        // barrier -> fragment reads -> MFMA -> softmax -> MFMA runs with little overlap at ~108 us.  Default: one tile per wave, the
         // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
         int tpw = g_dense_tpw == 0 ? 1 : g_dense_tpw;
         if (D > 64) tpw = 1;
