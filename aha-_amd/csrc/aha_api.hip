@@ -51,6 +51,10 @@ struct aha_ctx {
     std::vector<VLayerW> V;
     bf16 *p0w = nullptr, *p0b = nullptr, *p2w = nullptr, *p2b = nullptr;
     bf16 *post_ln_w = nullptr, *post_ln_b = nullptr;      // optional: only the vision_live.py contract uses the tower's post_layernorm
+    // optional: SigLIP attention-pooling head (pooler_output; models/vision_live.py:26-31, frame_token_cls)
+    bf16 *hd_probe = nullptr, *hd_in_w = nullptr, *hd_in_b = nullptr, *hd_out_w = nullptr, *hd_out_b = nullptr, *hd_ln_w = nullptr,
+         *hd_ln_b = nullptr, *hd_w1 = nullptr, *hd_b1 = nullptr, *hd_w2 = nullptr, *hd_b2 = nullptr, *hd_q = nullptr;
+    bool hd_q_ready = false;
     // tables
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
@@ -478,6 +482,22 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
         if ((rc = copy_vec(c, m, "vision.post_layernorm.weight", Dv, &c->post_ln_w, st))) return rc;
         if ((rc = copy_vec(c, m, "vision.post_layernorm.bias", Dv, &c->post_ln_b, st))) return rc;
     }
+    if (m.count("vision.head.probe")) {                     // all or nothing: need() reports the first missing tensor
+        const int64_t F = d.v_inter;
+        if ((rc = copy_vec(c, m, "vision.head.probe", Dv, &c->hd_probe, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.attention.in_proj_weight", (int64_t)3 * Dv * Dv, &c->hd_in_w, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.attention.in_proj_bias", 3 * Dv, &c->hd_in_b, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.attention.out_proj.weight", (int64_t)Dv * Dv, &c->hd_out_w, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.attention.out_proj.bias", Dv, &c->hd_out_b, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.layernorm.weight", Dv, &c->hd_ln_w, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.layernorm.bias", Dv, &c->hd_ln_b, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.mlp.fc1.weight", F * Dv, &c->hd_w1, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.mlp.fc1.bias", F, &c->hd_b1, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.mlp.fc2.weight", (int64_t)Dv * F, &c->hd_w2, st))) return rc;
+        if ((rc = copy_vec(c, m, "vision.head.mlp.fc2.bias", Dv, &c->hd_b2, st))) return rc;
+        if ((rc = dalloc(c, &c->hd_q, (size_t)Dv))) return rc;
+        c->hd_q_ready = false;
+    }
     if ((rc = copy_vec(c, m, "mm_projector.0.weight", (int64_t)H * Dv, &c->p0w, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.0.bias", H, &c->p0b, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.2.weight", (int64_t)H * H, &c->p2w, st))) return rc;
@@ -841,33 +861,76 @@ extern "C" int aha_vit_encode(aha_ctx* c, const uint8_t* frames, int n, void* ou
     return 0;
 }
 
-// The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode, frame_token_cls=False):
-// tower -> post_layernorm (last_hidden_state) -> adaptive_avg_pool2d to pooled x pooled -> connector.
-// Pooling happens BEFORE the projector, so the projector runs on pooled^2 rows per frame.
-extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, int n, int pooled, void* out_embeds,
-                                           aha_hip_stream st_) {
+// The encode contract of models/vision_live.py:11-31 (_siglip_vision_encode) and :34-54 (_clip_vision_encode):
+// tower -> last_hidden_state (SigLIP: + post_layernorm) -> adaptive_avg_pool2d to pooled x pooled (frame_token_pooled) and, with
+// frame_token_cls, the class token in front of it - SigLIP: pooler_output = the attention-pooling head on the post-layernormed
+// tokens (a learned probe attends over them, then x + mlp(layernorm(x))); CLIP: last_hidden_state[:, 0], returned only WITHOUT
+// pooling (the reference's torch.cat of [N, D] and [N, P, D] at vision_live.py:54 raises: refused here as well) -> connector.
+// Pooling happens BEFORE the projector, so the projector runs on cls + pooled^2 rows per frame.
+extern "C" int aha_vit_encode_live(aha_ctx* c, const uint8_t* frames, int n, int pooled, int cls, void* out_embeds, aha_hip_stream st_) {
     int rc = vit_check(c, frames, out_embeds, n);
     if (rc || n <= 0) return rc;
     const bool clip = c->d.v_kind == AHA_VISION_CLIP;
     if (!clip && !c->post_ln_w) return fail(c, AHA_E_NOENT, "vision.post_layernorm.{weight,bias} were not loaded");
-    if (pooled <= 0 || pooled > c->grid) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid");
+    if (pooled < 0 || pooled > c->grid || (pooled == 0 && !cls)) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid (0: class token only)");
+    if (cls && clip && pooled) return fail(c, AHA_E_INVAL, "_clip_vision_encode cannot return the class token together with pooled tokens (models/vision_live.py:54 raises)");
+    if (cls && !clip && !c->hd_probe) return fail(c, AHA_E_NOENT, "vision.head.* (attention-pooling head) was not loaded");
     hipStream_t st = (hipStream_t)st_;
     ORDER_VIT(c, st);
     const aha_model_desc& d = c->d;
-    const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden, prow = n * pooled * pooled;
+    const int Dv = d.v_hidden, rows = n * c->Tt, H = d.hidden, P = pooled * pooled, tok = (cls ? 1 : 0) + P, prow = n * tok;
     if ((rc = vit_tower(c, frames, n, st))) return rc;
+    const bf16* tokens = c->v_attn;                          // [n][tok][Dv] rows handed to the connector
     if (clip) {
-        // _clip_vision_encode (models/vision_live.py:34-49): last_hidden_state is the encoder output (transformers applies
-        // post_layernorm to the pooled class token only); the class token (last row of each frame here) is dropped by pooling
-        // over the first Np rows of each frame's Tt.
-        HIPCHK(c, aha_pool(c->v_x, c->v_attn, n, c->grid, pooled, Dv, 0, 3, c->Tt, st));
+        // last_hidden_state is the encoder output (transformers applies post_layernorm to the pooled class token only); the class
+        // token is the last row of each frame here.  Pooling runs over the first Np rows of each frame's Tt.
+        if (cls) HIPCHK(c, hipMemcpy2DAsync(c->v_attn, (size_t)Dv * 2, c->v_x + (size_t)(c->Tt - 1) * Dv, (size_t)c->Tt * Dv * 2, (size_t)Dv * 2, n,
+                                            hipMemcpyDeviceToDevice, st));
+        else HIPCHK(c, aha_pool(c->v_x, c->v_attn, n, c->grid, pooled, Dv, 0, 3, c->Tt, st));
     } else {
         HIPCHK(c, aha_layernorm(c->v_x, Dv, c->post_ln_w, c->post_ln_b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-        HIPCHK(c, aha_pool(c->v_h, c->v_attn, n, c->grid, pooled, Dv, 0, 3, 0, st));
+        if (P) HIPCHK(c, aha_pool(c->v_h, c->v_attn, n, c->grid, pooled, Dv, 0, 3, 0, st));
+        if (cls) {
+            const int F = d.v_inter, vhd = Dv / d.v_heads;
+            if (!c->hd_q_ready) {                            // the probe is a parameter: its query projection is computed once
+                HIPCHK(c, tile_gemm(c->hd_probe, Dv, 1, c->hd_in_w, Dv, Dv, Dv, c->hd_q, Dv, c->hd_in_b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+                c->hd_q_ready = true;
+            }
+            // K | V of every token (nn.MultiheadAttention's packed in_proj rows D..3D) into the tower's qkv buffer
+            HIPCHK(c, tile_gemm(c->v_h, Dv, rows, c->hd_in_w + (size_t)Dv * Dv, Dv, 2 * Dv, Dv, c->v_qkv + Dv, 3 * Dv, c->hd_in_b + Dv, ACT_NONE,
+                                nullptr, 0, nullptr, 0, 0, st));
+            bf16 *hb0 = c->v_p1, *hb1 = hb0 + (size_t)n * Dv, *hb2 = hb1 + (size_t)n * Dv, *cl = hb2 + (size_t)n * Dv;   // [n][Dv] each; v_p1 is idle until the connector
+            AttnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.q = c->hd_q; a.q_bs = 0; a.ldq = Dv;          // one query row, shared by every frame
+            a.k = c->v_qkv + Dv; a.v = c->v_qkv + 2 * Dv; a.kv_bs = (long)c->Tt * 3 * Dv; a.ldk = 3 * Dv;
+            a.out = hb0; a.o_bs = Dv; a.ldo = Dv;
+            a.T = 1; a.G = 1; a.Hkv = d.v_heads; a.Lk = c->Tt;
+            a.split_len = round_up(c->Tt, 64); a.n_splits = 1;
+            a.scale = 1.0f / sqrtf((float)vhd);
+            HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
+            HIPCHK(c, tile_gemm(hb0, Dv, n, c->hd_out_w, Dv, Dv, Dv, hb1, Dv, c->hd_out_b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+            HIPCHK(c, aha_layernorm(hb1, Dv, c->hd_ln_w, c->hd_ln_b, hb2, Dv, n, Dv, d.v_ln_eps, st));
+            HIPCHK(c, tile_gemm(hb2, Dv, n, c->hd_w1, Dv, F, Dv, c->v_f, c->Fp, c->hd_b1, ACT_GELU_TANH, nullptr, 0, nullptr, 0, 0, st));
+            HIPCHK(c, tile_gemm(c->v_f, c->Fp, n, c->hd_w2, F, Dv, F, cl, Dv, c->hd_b2, ACT_NONE, hb1, Dv, nullptr, 0, 0, st));
+            if (P) {                                         // [class token | pooled grid] per frame, assembled in the (now idle) tower output buffer
+                HIPCHK(c, hipMemcpy2DAsync(c->v_x, (size_t)tok * Dv * 2, cl, (size_t)Dv * 2, (size_t)Dv * 2, n, hipMemcpyDeviceToDevice, st));
+                HIPCHK(c, hipMemcpy2DAsync(c->v_x + Dv, (size_t)tok * Dv * 2, c->v_attn, (size_t)P * Dv * 2, (size_t)P * Dv * 2, n,
+                                           hipMemcpyDeviceToDevice, st));
+                tokens = c->v_x;
+            } else {
+                HIPCHK(c, hipMemcpyAsync(c->v_x, cl, (size_t)n * Dv * 2, hipMemcpyDeviceToDevice, st));
+                tokens = c->v_x;
+            }
+        }
     }
-    HIPCHK(c, tile_gemm(c->v_attn, Dv, prow, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
+    HIPCHK(c, tile_gemm(tokens, Dv, prow, c->p0w, Dv, H, Dv, c->v_p1, H, c->p0b, ACT_GELU_ERF, nullptr, 0, nullptr, 0, 0, st));
     HIPCHK(c, tile_gemm(c->v_p1, H, prow, c->p2w, H, H, H, (bf16*)out_embeds, H, c->p2b, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
     return 0;
+}
+extern "C" int aha_vit_encode_pooled_first(aha_ctx* c, const uint8_t* frames, int n, int pooled, void* out_embeds, aha_hip_stream st) {
+    if (pooled <= 0) return c ? fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid") : AHA_E_INVAL;
+    return aha_vit_encode_live(c, frames, n, pooled, 0, out_embeds, st);
 }
 
 extern "C" int aha_vit_last_tower_output(aha_ctx* c, int n_frames, void* out, aha_hip_stream st) {

@@ -46,6 +46,7 @@ SYMBOLS = [
     ("aha_last_error", C.c_char_p, [_P]),
     ("aha_vit_encode", _I, [_P, _P, _I, _P, _P]),
     ("aha_vit_encode_pooled_first", _I, [_P, _P, _I, _I, _P, _P]),
+    ("aha_vit_encode_live", _I, [_P, _P, _I, _I, _I, _P, _P]),
     ("aha_vit_last_tower_output", _I, [_P, _I, _P, _P]),
     ("aha_frame_ingest", _I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     ("aha_embed_tokens", _I, [_P, _P, _I, _P, _P]),

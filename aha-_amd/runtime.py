@@ -229,18 +229,20 @@ class Runtime:
                                             out.data_ptr(), _cur_stream()))
         return out
 
-    def vision_live_embed(self, frames_u8: torch.Tensor, pooled: int = 7) -> torch.Tensor:
-        """models/vision_live.py:11-31 contract + connector: tower -> post_layernorm -> adaptive average pool to
-        pooled x pooled -> mm_projector.  uint8 [N,3,S,S] -> bf16 [N*pooled*pooled, H]."""
+    def vision_live_embed(self, frames_u8: torch.Tensor, pooled: int = 7, cls: bool = False) -> torch.Tensor:
+        """models/vision_live.py:11-31 / :34-54 contract + connector: tower -> last_hidden_state (SigLIP: post_layernorm) ->
+        adaptive average pool to pooled x pooled, with `cls` (frame_token_cls) the class token in front of it (SigLIP: the
+        attention-pooling head's pooler_output; pooled = 0: the class token alone) -> mm_projector.
+        uint8 [N,3,S,S] -> bf16 [N*(cls + pooled*pooled), H]."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4
         frames_u8 = frames_u8.contiguous()
-        n = frames_u8.shape[0]
-        out = torch.empty((n * pooled * pooled, self.hidden_size), dtype=torch.bfloat16, device=self.device)
+        n, tok = frames_u8.shape[0], (1 if cls else 0) + pooled * pooled
+        out = torch.empty((n * tok, self.hidden_size), dtype=torch.bfloat16, device=self.device)
         step = self.desc.max_vit_frames
         for i in range(0, n, step):
             m = min(step, n - i)
-            self._chk(self.lib.aha_vit_encode_pooled_first(self.ctx, frames_u8[i:i + m].data_ptr(), m, pooled,
-                                                           out[i * pooled * pooled:].data_ptr(), _cur_stream()))
+            self._chk(self.lib.aha_vit_encode_live(self.ctx, frames_u8[i:i + m].data_ptr(), m, int(pooled), int(bool(cls)),
+                                                   out[i * tok:].data_ptr(), _cur_stream()))
         return out
 
     def tower_output(self, n_frames: int) -> torch.Tensor:

@@ -97,6 +97,30 @@ def make_weights(cfg: LiveConfig, *, device="cpu", dtype=torch.bfloat16, jitter:
     return out
 
 
+def make_vision_head_weights(cfg: LiveConfig, *, device="cpu", dtype=torch.bfloat16, std: float = 0.05) -> Dict[str, torch.Tensor]:
+    """The SigLIP vision model's tail that only the models/vision_live.py contract reads: post_layernorm and the attention-
+    pooling head (`head.*`: probe, nn.MultiheadAttention in/out projections, layernorm, MLP).  Seeded like make_weights."""
+    v = cfg.vision
+    d, f = v.hidden_size, v.intermediate_size
+    specs = [("vision.post_layernorm.weight", (d,), "norm_w"), ("vision.post_layernorm.bias", (d,), "b"),
+             ("vision.head.probe", (1, 1, d), "probe"),
+             ("vision.head.attention.in_proj_weight", (3 * d, d), "w"), ("vision.head.attention.in_proj_bias", (3 * d,), "b"),
+             ("vision.head.attention.out_proj.weight", (d, d), "w"), ("vision.head.attention.out_proj.bias", (d,), "b"),
+             ("vision.head.layernorm.weight", (d,), "norm_w"), ("vision.head.layernorm.bias", (d,), "b"),
+             ("vision.head.mlp.fc1.weight", (f, d), "w"), ("vision.head.mlp.fc1.bias", (f,), "b"),
+             ("vision.head.mlp.fc2.weight", (d, f), "w"), ("vision.head.mlp.fc2.bias", (d,), "b")]
+    out: Dict[str, torch.Tensor] = {}
+    dev = torch.device(device)
+    for name, shape, kind in specs:
+        g = torch.Generator(device=dev)
+        g.manual_seed(zlib.crc32(name.encode()))
+        t = torch.empty(shape, device=dev, dtype=torch.float32).normal_(0.0, 1.0 if kind == "probe" else (0.1 if kind == "norm_w" else std), generator=g)
+        if kind == "norm_w":
+            t += 1.0
+        out[name] = t.to(dtype)
+    return out
+
+
 def make_frames(n: int, resolution: int, *, seed: int = 0, device="cpu") -> torch.Tensor:
     """uint8 [n,3,S,S] RGB CHW, the layout load_video_for_testing hands to the driver
     (test/inference.py:497-582)."""

@@ -131,6 +131,12 @@ int aha_vit_encode(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* o
  * class token dropped, same pooling and connector.  out_embeds: bf16 [n*pooled*pooled][hidden] */
 int aha_vit_encode_pooled_first(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, int pooled, void* out_embeds,
                                 aha_hip_stream st);
+/* The same contract with frame_token_cls (models/vision_live.py:26-31 / :50-54; models/arguments_live.py:20): cls != 0 puts the class
+ * token in front of each frame's pooled tokens.  SigLIP: the vision model's pooler_output, i.e. its attention-pooling head on the
+ * post-layernormed tokens (needs "vision.head.*": probe, attention.in_proj_{weight,bias}, attention.out_proj, layernorm, mlp.fc1/fc2);
+ * CLIP: last_hidden_state[:, 0], which the reference can return only without pooling (its torch.cat at :54 raises otherwise; AHA_E_INVAL
+ * here).  pooled = 0 with cls: the class token alone.  out_embeds: bf16 [n*(cls + pooled*pooled)][hidden] */
+int aha_vit_encode_live(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, int pooled, int cls, void* out_embeds, aha_hip_stream st);
 /* parity-test tap: copy the tower output of the last encode, bf16 [n_frames*Np][v_hidden] */
 int aha_vit_last_tower_output(aha_ctx* ctx, int n_frames, void* out, aha_hip_stream st);
 

@@ -116,21 +116,49 @@ class OracleVision:
         return x.reshape(-1, x.shape[-1])
 
 
+def siglip_pooling_head(ov: "OracleVision", last_hidden_state: torch.Tensor) -> torch.Tensor:
+    """SiglipVisionTransformer.head = SiglipMultiheadAttentionPoolingHead (transformers modeling_siglip.py; `pooler_output`
+    of the vision model, read by models/vision_live.py:27 when frame_token_cls is set): a learned probe attends over the
+    post-layernormed tokens (nn.MultiheadAttention, batch_first), then x + mlp(layernorm(x)).  [N,Np,Dv] -> [N,Dv].
+    Pinned against the local transformers class in tests/test_oracle_models.py."""
+    v, w = ov.v, ov.w
+    n, _, d = last_hidden_state.shape
+    nh, hd = v.num_attention_heads, v.head_dim
+    wi, bi = w["vision.head.attention.in_proj_weight"], w["vision.head.attention.in_proj_bias"]
+    q = F.linear(w["vision.head.probe"].reshape(1, 1, d).expand(n, 1, d), wi[:d], bi[:d])
+    k = F.linear(last_hidden_state, wi[d:2 * d], bi[d:2 * d])
+    vv = F.linear(last_hidden_state, wi[2 * d:], bi[2 * d:])
+    q = q.view(n, 1, nh, hd).transpose(1, 2)
+    k = k.view(n, -1, nh, hd).transpose(1, 2)
+    vv = vv.view(n, -1, nh, hd).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, vv, scale=hd ** -0.5).transpose(1, 2).reshape(n, 1, d)
+    x = F.linear(o, w["vision.head.attention.out_proj.weight"], w["vision.head.attention.out_proj.bias"])
+    h = F.layer_norm(x, (d,), w["vision.head.layernorm.weight"], w["vision.head.layernorm.bias"], v.layer_norm_eps)
+    h = F.gelu(F.linear(h, w["vision.head.mlp.fc1.weight"], w["vision.head.mlp.fc1.bias"]), approximate="tanh")
+    x = x + F.linear(h, w["vision.head.mlp.fc2.weight"], w["vision.head.mlp.fc2.bias"])
+    return x[:, 0]
+
+
 def vision_live_encode(ov: "OracleVision", frames_u8: torch.Tensor, post_ln_w: torch.Tensor, post_ln_b: torch.Tensor,
-                       frame_token_pooled=(7, 7)) -> torch.Tensor:
-    """models/vision_live.py:11-31 (_siglip_vision_encode with frame_token_cls=False) then LiveMixin.visual_embed's
-    connector (models/modeling_live.py:31-37; that model class has no post_projector_pooling):
+                       frame_token_pooled=(7, 7), frame_token_cls: bool = False) -> torch.Tensor:
+    """models/vision_live.py:11-31 (_siglip_vision_encode) then LiveMixin.visual_embed's connector
+    (models/modeling_live.py:31-37; that model class has no post_projector_pooling):
       normalize(frames * 1/255, .5, .5) -> vision_model(frames).last_hidden_state (= tower + post_layernorm,
-      transformers modeling_siglip.py:622-644) -> adaptive_avg_pool2d over the patch grid -> connector.
-    Returns [N*ph*pw, H]."""
+      transformers modeling_siglip.py:622-644) -> adaptive_avg_pool2d over the patch grid (frame_token_pooled), and with
+      frame_token_cls the pooling head's output in front of it (vision_live.py:26-31) -> connector.
+    Returns [N*(cls + ph*pw), H]; frame_token_pooled = None with frame_token_cls gives the class token alone [N, H]."""
     dt, v = ov.dtype, ov.v
     x = ov.tower(preprocess(frames_u8, dt))
     x = F.layer_norm(x, (v.hidden_size,), post_ln_w.to(dt), post_ln_b.to(dt), v.layer_norm_eps)
     n, _, d = x.shape
-    s = int(math.sqrt(x.shape[1]))
-    sp = F.adaptive_avg_pool2d(x.reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))
-    sp = sp.flatten(2, 3).permute(0, 2, 1)
-    y = ov.connector(sp)
+    toks = []
+    if frame_token_cls:
+        toks.append(siglip_pooling_head(ov, x)[:, None])
+    if frame_token_pooled:
+        s = int(math.sqrt(x.shape[1]))
+        sp = F.adaptive_avg_pool2d(x.reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))
+        toks.append(sp.flatten(2, 3).permute(0, 2, 1))
+    y = ov.connector(torch.cat(toks, dim=1))
     return y.reshape(-1, y.shape[-1])
 
 
@@ -187,11 +215,17 @@ def clip_visual_embed(ov: "OracleCLIPVision", frames_u8: torch.Tensor) -> torch.
     return x.reshape(-1, x.shape[-1])
 
 
-def clip_live_encode(ov: "OracleCLIPVision", frames_u8: torch.Tensor, frame_token_pooled=(7, 7)) -> torch.Tensor:
-    """models/vision_live.py:34-54 (_clip_vision_encode, frame_token_cls=False) then LiveMixin.visual_embed's connector:
+def clip_live_encode(ov: "OracleCLIPVision", frames_u8: torch.Tensor, frame_token_pooled=(7, 7), frame_token_cls: bool = False) -> torch.Tensor:
+    """models/vision_live.py:34-54 (_clip_vision_encode) then LiveMixin.visual_embed's connector:
     normalize with the OpenAI CLIP constants -> last_hidden_state -> drop the class token -> adaptive_avg_pool2d over the
-    patch grid -> connector.  Returns [N*ph*pw, H]."""
+    patch grid -> connector.  Returns [N*ph*pw, H].  frame_token_cls without pooling returns the class token alone,
+    last_hidden_state[:, 0] (vision_live.py:50-53) -> [N, H]; with pooling the reference's torch.cat of a 2-D and a 3-D
+    tensor (vision_live.py:54) raises, and so does this."""
     x = ov.tower(preprocess_clip(frames_u8, ov.dtype))
+    if frame_token_cls:
+        if frame_token_pooled:
+            raise RuntimeError("_clip_vision_encode: torch.cat of [N, D] and [N, P, D] (models/vision_live.py:54)")
+        return ov.connector(x[:, 0])
     n, t, d = x.shape
     s = int(math.sqrt(t))                                          # the reference takes sqrt of Np + 1 and truncates
     sp = F.adaptive_avg_pool2d(x[:, 1:].reshape(n, s, s, d).permute(0, 3, 1, 2), tuple(frame_token_pooled))

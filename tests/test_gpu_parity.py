@@ -589,6 +589,53 @@ def test_vision_live_contract_pooled_first():
     rt.close()
 
 
+def test_vision_live_contract_with_class_token():
+    """frame_token_cls (models/vision_live.py:26-31, :50-54): SigLIP's pooler_output - the attention-pooling head over the
+    post-layernormed tokens - in front of the pooled grid, and alone; CLIP's class token alone, and the combination the
+    reference itself cannot produce is refused.  The oracle's head is pinned against transformers (tests/test_oracle_models.py)."""
+    from aha_amd.config import LiveConfig, LMConfig, VisionConfig
+    from aha_amd.runtime import AhaError
+    from aha_amd.synth import make_vision_head_weights
+    from oracle.vision_tower import OracleCLIPVision, OracleVision, clip_live_encode, vision_live_encode
+    lm = LMConfig(hidden_size=256, num_hidden_layers=1, num_attention_heads=4, num_key_value_heads=2, head_dim=64,
+                  intermediate_size=512, vocab_size=512)
+    cfg = LiveConfig(vision=VisionConfig(image_size=378, patch_size=14, hidden_size=128, num_hidden_layers=2,
+                                         num_attention_heads=2, intermediate_size=256), lm=lm, name="vlive_cls")
+    w = make_weights(cfg, dtype=torch.bfloat16, jitter=True)
+    w.update(make_vision_head_weights(cfg, dtype=torch.bfloat16))
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=3, max_positions=1024)
+    fr = make_frames(3, 378, seed=6)
+    ov = OracleVision(cfg, w, torch.bfloat16)
+    plw, plb = w["vision.post_layernorm.weight"], w["vision.post_layernorm.bias"]
+    for pooled, shape in ((7, (3 * 50, 256)), (0, (3, 256))):
+        want = vision_live_encode(ov, fr, plw, plb, (pooled, pooled) if pooled else None, frame_token_cls=True).float()
+        got = rt.vision_live_embed(fr.cuda(), pooled=pooled, cls=True).float().cpu()
+        assert got.shape == want.shape == shape
+        assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item()), pooled
+    # the class-token rows and the grid rows are each what they are alone
+    both = rt.vision_live_embed(fr.cuda(), pooled=7, cls=True).view(3, 50, 256)
+    assert torch.equal(both[:, 1:].reshape(-1, 256), rt.vision_live_embed(fr.cuda(), pooled=7))
+    assert torch.equal(both[:, 0], rt.vision_live_embed(fr.cuda(), pooled=0, cls=True))
+    rt.close()
+    del w["vision.head.probe"]
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=3, max_positions=1024)
+    with pytest.raises(AhaError):
+        rt.vision_live_embed(fr.cuda(), pooled=7, cls=True)           # head not loaded: loud
+    rt.close()
+    ccfg = LiveConfig(vision=VisionConfig(image_size=56, patch_size=14, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                          intermediate_size=256, kind="clip"), lm=lm, name="clive_cls")
+    cw = make_weights(ccfg, dtype=torch.bfloat16, jitter=True)
+    crt = _rt(ccfg, cw, max_step_tokens=64, max_vit_frames=3, max_positions=1024)
+    cfr = make_frames(3, 56, seed=7)
+    want = clip_live_encode(OracleCLIPVision(ccfg, cw, torch.bfloat16), cfr, None, frame_token_cls=True).float()
+    got = crt.vision_live_embed(cfr.cuda(), pooled=0, cls=True).float().cpu()
+    assert got.shape == want.shape == (3, 256)
+    assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
+    with pytest.raises(AhaError):
+        crt.vision_live_embed(cfr.cuda(), pooled=2, cls=True)
+    crt.close()
+
+
 # ---------------------------------------------------------------------------------------------------
 # frame ingest (integer path: bit-exact)
 # ---------------------------------------------------------------------------------------------------

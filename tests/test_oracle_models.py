@@ -85,6 +85,43 @@ def test_vision_matches_golden_and_transformers():
         assert (hs.float() - yo.float()).abs().max().item() <= (2e-5 if dt == torch.float32 else 0.04)
 
 
+def test_siglip_pooling_head_matches_transformers_pooler_output():
+    """models/vision_live.py:26-31 (frame_token_cls): `pooler_output` of the SigLIP vision model = its attention-pooling head on
+    the post-layernormed tokens.  The oracle's restatement against the local transformers SiglipVisionModel, fp32 and bf16,
+    and the encode contract's token order (class token first, then the pooled grid)."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from aha_amd.synth import make_vision_head_weights
+    from oracle.vision_tower import siglip_pooling_head, vision_live_encode
+    cfg = preset("tiny")
+    v = cfg.vision
+    w = make_weights(cfg, dtype=torch.float32, jitter=True)
+    w.update(make_vision_head_weights(cfg, dtype=torch.float32))
+    fr = make_frames(2, v.image_size, seed=3)
+    vc = SiglipVisionConfig(hidden_size=v.hidden_size, intermediate_size=v.intermediate_size,
+                            num_hidden_layers=v.num_hidden_layers, num_attention_heads=v.num_attention_heads,
+                            image_size=v.image_size, patch_size=v.patch_size, layer_norm_eps=v.layer_norm_eps,
+                            hidden_act="gelu_pytorch_tanh", attn_implementation="sdpa")
+    for dt in (torch.float32, torch.bfloat16):
+        vm = SiglipVisionModel(vc).to(dt).eval()
+        missing = vm.load_state_dict({k[len("vision."):]: t.to(dt) for k, t in w.items() if k.startswith("vision.")}, strict=True)
+        px = preprocess(fr, dt)
+        with torch.no_grad():
+            out = vm(pixel_values=px)
+        ov = OracleVision(cfg, w, dt)
+        x = torch.nn.functional.layer_norm(ov.tower(px), (v.hidden_size,), ov.w["vision.post_layernorm.weight"],
+                                           ov.w["vision.post_layernorm.bias"], v.layer_norm_eps)
+        assert (x.float() - out.last_hidden_state.float()).abs().max().item() <= (3e-5 if dt == torch.float32 else 0.06)
+        got = siglip_pooling_head(ov, out.last_hidden_state)           # same input: isolates the head
+        tol = 3e-5 if dt == torch.float32 else 0.03 * max(1.0, out.pooler_output.float().abs().max().item())
+        assert (got.float() - out.pooler_output.float()).abs().max().item() <= tol, dt
+    ov = OracleVision(cfg, w, torch.float32)
+    plw, plb = w["vision.post_layernorm.weight"], w["vision.post_layernorm.bias"]
+    both = vision_live_encode(ov, fr, plw, plb, (2, 2), frame_token_cls=True).view(2, 5, -1)
+    only_sp = vision_live_encode(ov, fr, plw, plb, (2, 2)).view(2, 4, -1)
+    only_cls = vision_live_encode(ov, fr, plw, plb, None, frame_token_cls=True).view(2, 1, -1)
+    assert torch.allclose(both[:, 1:], only_sp, atol=1e-6) and torch.allclose(both[:, :1], only_cls, atol=1e-6)
+
+
 def test_clip_tower_matches_transformers_and_encode_contract():
     """The CLIP half of models/vision_live.py (_clip_vision_encode): the oracle's CLIP tower against local transformers
     CLIPVisionModel.last_hidden_state (class token, pre_layrnorm, quick_gelu, no post-layernorm), and the encode contract
