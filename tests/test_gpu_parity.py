@@ -464,6 +464,18 @@ def test_reference_faithful_vision_shapes_head_dim_72():
     assert (got_e - want_e).abs().max().item() <= 0.03 * max(1.0, want_e.abs().max().item())
     assert got_e.shape == (2 * 49, 256)
     rt.close()
+    # the vision_live.py contract at this geometry, class token included: the attention-pooling head with 72-wide heads
+    # (one query row through the zero-padded 128-wide attention template) and the 4304-wide MLP
+    from aha_amd.synth import make_vision_head_weights
+    from oracle.vision_tower import vision_live_encode
+    w.update(make_vision_head_weights(cfg, dtype=torch.bfloat16))
+    rt = _rt(cfg, w, max_step_tokens=64, max_vit_frames=2, max_positions=1024)
+    want = vision_live_encode(OracleVision(cfg, w, torch.bfloat16), fr, w["vision.post_layernorm.weight"],
+                              w["vision.post_layernorm.bias"], (7, 7), frame_token_cls=True).float()
+    got = rt.vision_live_embed(fr.cuda(), pooled=7, cls=True).float().cpu()
+    assert got.shape == want.shape == (2 * 50, 256)
+    assert (got - want).abs().max().item() <= 0.03 * max(1.0, want.abs().max().item())
+    rt.close()
 
 
 def test_frozen_static_fusion_is_bit_identical(tiny128):
