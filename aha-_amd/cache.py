@@ -1,8 +1,10 @@
-"""Cache objects with the reference's class names and constructor arguments
-(test/sink_cache.py:8-19, test/sliding_window_cache.py:5-15, test/static_cache.py:5-16).  Each is a
-handle on a preallocated ring KV buffer inside the runtime (aha_stream); `update()` is not exposed
-because the cache update happens inside the fused LM step (qkv_finish writes K/V straight into
-the ring, sink_rerotate re-rotates kept keys in place)."""
+"""Cache objects with the reference's class names, constructor arguments and operator interface
+(test/sink_cache.py:8-19,57-80, test/sliding_window_cache.py:5-44, test/static_cache.py:5-36).  Each is a
+handle on a preallocated ring KV buffer inside the runtime (aha_stream).  The fused LM step updates
+the cache itself (qkv_finish writes K/V straight into the ring, sink_rerotate re-rotates kept keys in
+place); `update(key_states, value_states, layer_idx, cache_kwargs)` is the same operation exposed at the
+reference's operator level (aha_cache_update), for callers that drive the cache from their own
+attention code the way transformers does."""
 from __future__ import annotations
 
 from typing import Optional
@@ -25,6 +27,18 @@ class _BoundCache:
 
     def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
         return 0 if self.stream is None else self.stream.get_seq_length()
+
+    def update(self, key_states, value_states, layer_idx: int, cache_kwargs=None):
+        """Cache.update of the reference: append this layer's new (already rotated) keys / values, bf16 [1, kv_heads, T,
+        head_dim], evicting / re-rotating as the policy says, and return the (K, V) the attention must see, [1, kv_heads, L,
+        head_dim].  As in the reference the layer_idx == 0 call advances the bookkeeping (seen tokens, eviction) and the other
+        layers of the step follow in order.  `cache_kwargs` ("sin", "cos", "cache_position", ...) is accepted and ignored: the
+        re-rotation coefficients come from the runtime's own RoPE table (bit-identical to SinkCache's, test/sink_cache.py:35-55)."""
+        if self.stream is None:
+            raise RuntimeError("cache is not bound to a runtime: call cache.bind(runtime) (or hand it to LiveLlavaModel) first")
+        if key_states.dim() == 4 and key_states.shape[0] != 1:
+            raise ValueError("one stream per cache object: batch dimension must be 1")
+        return self.stream.rt.cache_update(self.stream, int(layer_idx), key_states, value_states)
 
     def get_max_length(self) -> Optional[int]:
         return self.window_length

@@ -59,7 +59,6 @@ struct aha_ctx {
     bf16 *rope_cos = nullptr, *rope_sin = nullptr;
     int n_pos = 0;
     std::map<std::tuple<int, int, int>, std::pair<bf16*, bf16*>> rerot;
-    std::map<std::tuple<int, int, int>, hipStream_t> rerot_stream;   // stream a device-built table was enqueued on (later LM work is ordered behind it by ORDER_LM)
     // HIP-graph replay of frozen TrulyStaticCache steps (tuning "use_graph"): cached executables keyed by the exact step
     // device-resident step descriptor: written to a pinned ring slot and uploaded once per step (1 KB), so kernels take a
     // constant pointer and a captured graph does not bake the per-step stream state in
@@ -127,6 +126,7 @@ struct aha_stream {
     int policy, W, sink, cap;
     bf16 *k = nullptr, *v = nullptr;
     int len = 0, head = 0, seen = 0;
+    bool poisoned = false;               // a step failed after destructive device work was enqueued: refuse steps until aha_stream_reset
     int semantics = AHA_ATTN_TRAILING;
     int pos_off = 0;                     // added to the RoPE position of new token 0 (aha_stream_set_position_offset)
     // operator-level aha_cache_update: the step planned by layer 0's call, followed by the other layers of that step
@@ -275,6 +275,7 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     if (c->vit_done) hipEventDestroy(c->vit_done);
     for (void* p : c->pinned) hipHostFree(p);
     if (c->gen_pin) hipHostFree(c->gen_pin);
+    if (c->gen_out) { hipFree(c->gen_out); hipFree(c->gen_tmp); }
     if (c->gen_ev) hipEventDestroy(c->gen_ev);
     for (auto& kv : c->ingest_tabs) if (kv.second.ready) hipEventDestroy(kv.second.ready);
     for (void* p : c->allocs) hipFree(p);
@@ -579,6 +580,7 @@ extern "C" int aha_stream_reset(aha_stream* s) {
     if (!s) return AHA_E_INVAL;
     s->len = s->head = s->seen = 0;
     s->op_valid = false;
+    s->poisoned = false;
     return 0;
 }
 extern "C" int aha_stream_seq_length(const aha_stream* s) { return s ? s->len : AHA_E_INVAL; }
@@ -875,6 +877,9 @@ extern "C" int aha_vit_encode_live(aha_ctx* c, const uint8_t* frames, int n, int
     if (pooled < 0 || pooled > c->grid || (pooled == 0 && !cls)) return fail(c, AHA_E_RANGE, "pooled grid must be in 1..patch grid (0: class token only)");
     if (cls && clip && pooled) return fail(c, AHA_E_INVAL, "_clip_vision_encode cannot return the class token together with pooled tokens (models/vision_live.py:54 raises)");
     if (cls && !clip && !c->hd_probe) return fail(c, AHA_E_NOENT, "vision.head.* (attention-pooling head) was not loaded");
+    // the token assembly and the connector write n * (cls + pooled^2) rows into workspaces sized max_vit_frames * Tt rows
+    if ((long)n * ((cls ? 1 : 0) + pooled * pooled) > (long)c->d.max_vit_frames * c->Tt)
+        return fail(c, AHA_E_RANGE, "n_frames * (class token + pooled^2) exceeds the vision workspace (max_vit_frames * tokens per frame)");
     hipStream_t st = (hipStream_t)st_;
     ORDER_VIT(c, st);
     const aha_model_desc& d = c->d;
@@ -1059,6 +1064,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     for (int b = 0; b < B; ++b) {
         aha_stream* s = streams[b];
         if (!s || s->ctx != c) return fail(c, AHA_E_INVAL, "bad stream handle");
+        if (s->poisoned) return fail(c, AHA_E_INVAL, "stream state is undefined after a failed step (keys were re-rotated / slots overwritten): call aha_stream_reset");
         for (int b2 = 0; b2 < b; ++b2)
             if (streams[b2] == s && !(s->policy == AHA_CACHE_STATIC && s->len > 0))
                 return fail(c, AHA_E_INVAL, "a stream may appear only once per step (except a frozen TrulyStaticCache stream, whose "
@@ -1069,13 +1075,18 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     sd.B = B;
     sd.T = T;
     // Host bookkeeping is advanced by plan_stream BEFORE any device work is enqueued; this guard puts every stream back
-    // if anything after it fails (planning, table build, descriptor upload, a launch, graph capture / replay), so a
-    // caller that retries or continues never attends over slots that were never written.
+    // if anything fails before the first destructive launch (planning, descriptor upload), so a caller may retry.  Once
+    // device work that changes the caches has been enqueued (in-place re-rotation of kept keys, ring slots overwritten by
+    // the K/V append) a retry would rotate the kept keys a second time: the streams are then marked poisoned instead of
+    // rolled back and refuse further steps until aha_stream_reset.
     struct Rollback {
-        aha_stream* const* streams; int n = 0; int saved[AHA_MAX_B][3]; bool armed = true;
+        aha_stream* const* streams; int n = 0; int saved[AHA_MAX_B][3]; bool armed = true, destructive = false;
         ~Rollback() {
             if (!armed) return;
-            for (int b = n - 1; b >= 0; --b) { streams[b]->len = saved[b][0]; streams[b]->head = saved[b][1]; streams[b]->seen = saved[b][2]; }
+            for (int b = n - 1; b >= 0; --b) {
+                if (destructive) { streams[b]->poisoned = true; continue; }
+                streams[b]->len = saved[b][0]; streams[b]->head = saved[b][1]; streams[b]->seen = saved[b][2];
+            }
         }
     } guard{streams};
     for (int b = 0; b < B; ++b) {
@@ -1087,22 +1098,11 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
         if (rc) return rc;
     }
     ORDER_LM(c, st);
-    // SinkCache re-rotation tables this step needs, built on the device from the RoPE table the first time a
-    // (window, n_sink, T) combination evicts: asynchronous on `st`, no host round trip (test/sink_cache.py:35-55)
-    for (int b = 0; b < B; ++b) {
-        if (sd.s[b].n_rerot == 0) continue;
-        const aha_stream* s = streams[b];
-        const auto key = std::make_tuple(s->W, s->sink, T);
-        if (c->rerot.count(key)) continue;
-        if (s->W > c->n_pos) return fail(c, AHA_E_RANGE, "SinkCache window exceeds the RoPE table");
-        const int rows = s->W - s->sink - T;
-        bf16 *pc, *ps;
-        int rc;
-        if ((rc = dalloc(c, &pc, (size_t)rows * Dh)) || (rc = dalloc(c, &ps, (size_t)rows * Dh))) return rc;
-        HIPCHK(c, aha_rerot_table(c->rope_cos, c->rope_sin, Dh, s->sink, T, rows, pc, ps, st));
-        c->rerot[key] = {pc, ps};
-        c->rerot_stream[key] = st;
-    }
+    // SinkCache re-rotation (test/sink_cache.py:35-55): sink_rerotate_kernel computes the coefficients from the RoPE table on the
+    // fly unless the caller registered a (window, n_sink, T) table (aha_ctx_set_rerotation_table) - nothing is allocated or built
+    // inside a per-frame call.  The rows it reads are RoPE positions sink .. window - 1.
+    for (int b = 0; b < B; ++b)
+        if (sd.s[b].n_rerot > 0 && streams[b]->W > c->n_pos) return fail(c, AHA_E_RANGE, "SinkCache window exceeds the RoPE table");
     c->last_weight_bytes = c->last_kv_bytes = c->last_flops = 0;
     for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
 
@@ -1139,10 +1139,12 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
                     nmax = sd.s[b2].n_rerot > nmax ? sd.s[b2].n_rerot : nmax;
                 }
             }
-            auto tb = c->rerot[std::make_tuple(streams[b]->W, streams[b]->sink, T)];
+            std::pair<bf16*, bf16*> tb{nullptr, nullptr};
+            if (auto it = c->rerot.find(std::make_tuple(streams[b]->W, streams[b]->sink, T)); it != c->rerot.end()) tb = it->second;
             const bool timed = (c->time_gemm >> GK_REROT) & 1;
             if (timed) { if (int rc = timed_begin(c, GK_REROT, st)) return rc; }
-            HIPCHK(c, aha_sink_rerotate(c->sd_dev, mask, B, nmax, tb.first, tb.second, d.layers, d.kv_heads, Dh, st));
+            guard.destructive = true;
+            HIPCHK(c, aha_sink_rerotate(c->sd_dev, mask, B, nmax, tb.first, tb.second, c->rope_cos, c->rope_sin, d.layers, d.kv_heads, Dh, st));
             if (timed) {
                 double by = 0;                               // algorithmic: every kept key of every layer read and written once
                 for (int b2 = 0; b2 < B; ++b2)
@@ -1299,6 +1301,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     // policy, any stream - and is replayed; it is captured on a private stream the second time a shape is seen (every lazily
     // set kernel attribute has been set by then); any failure falls back to direct launches for that shape.  The descriptor
     // upload, the sink re-rotation and the input / score copies stay outside the graph.
+    // from here on the launches overwrite ring slots; where a stream evicts this step, a failure can no longer be rolled back
+    for (int b = 0; b < B; ++b)
+        if (sd.s[b].write_base >= 0 && guard.saved[b][0] + sd.s[b].write_count > sd.s[b].len_after) guard.destructive = true;
     const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
     const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0);
     // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
@@ -1584,6 +1589,7 @@ extern "C" int aha_cache_update(aha_ctx* c, aha_stream* s, int layer, const void
     if (!c || !s || s->ctx != c || !k_new || !v_new || T <= 0) return AHA_E_INVAL;
     const aha_model_desc& d = c->d;
     if (layer < 0 || layer >= d.layers) return fail(c, AHA_E_RANGE, "layer out of range");
+    if (s->poisoned) return fail(c, AHA_E_INVAL, "stream state is undefined after a failed step: call aha_stream_reset");
     hipStream_t st = (hipStream_t)st_;
     ORDER_LM(c, st);
     struct { StreamStep& ss; int& T; int& next_layer; bool& valid; } op{s->op_ss, s->op_T, s->op_next_layer, s->op_valid};
@@ -1599,19 +1605,15 @@ extern "C" int aha_cache_update(aha_ctx* c, aha_stream* s, int layer, const void
         return fail(c, AHA_E_INVAL, "aha_cache_update: layers of a step must be updated in order 0..L-1 with the same T");
     op.next_layer = layer + 1;
     const bf16 *rc_ = nullptr, *rs_ = nullptr;
-    if (op.ss.n_rerot > 0) {
-        const auto key = std::make_tuple(s->W, s->sink, T);
-        if (!c->rerot.count(key)) {
-            const int rows = s->W - s->sink - T;
-            bf16 *pc, *ps;
-            int rc;
-            if ((rc = dalloc(c, &pc, (size_t)rows * d.head_dim)) || (rc = dalloc(c, &ps, (size_t)rows * d.head_dim))) return rc;
-            HIPCHK(c, aha_rerot_table(c->rope_cos, c->rope_sin, d.head_dim, s->sink, T, rows, pc, ps, st));
-            c->rerot[key] = {pc, ps};
-        }
-        rc_ = c->rerot[key].first; rs_ = c->rerot[key].second;
+    if (op.ss.n_rerot > 0)                                  // a registered table if there is one, else coefficients on the fly
+        if (auto it = c->rerot.find(std::make_tuple(s->W, s->sink, T)); it != c->rerot.end()) { rc_ = it->second.first; rs_ = it->second.second; }
+    if (hipError_t e = aha_cache_update_layer(&op.ss, layer, d.kv_heads, d.head_dim, T, (const bf16*)k_new, (const bf16*)v_new, rc_, rs_, c->rope_cos,
+                                              c->rope_sin, st); e != hipSuccess) {
+        // the step cannot be completed: layers already updated hold the new state, the rest the old one
+        op.valid = false;
+        s->poisoned = true;
+        return fail(c, AHA_E_HIP, std::string("aha_cache_update_layer: ") + hipGetErrorString(e));
     }
-    HIPCHK(c, aha_cache_update_layer(&op.ss, layer, d.kv_heads, d.head_dim, T, (const bf16*)k_new, (const bf16*)v_new, rc_, rs_, st));
     if (out_k) { int rc = aha_stream_export_kv(c, s, layer, 0, out_k, st_); if (rc) return rc; }
     if (out_v) { int rc = aha_stream_export_kv(c, s, layer, 1, out_v, st_); if (rc) return rc; }
     return 0;
@@ -1623,9 +1625,17 @@ extern "C" int aha_cache_update(aha_ctx* c, aha_stream* s, int layer, const void
 // the data path); the host only polls the 8-byte id behind each step to honour the early stop exactly - this call therefore
 // blocks until the response is complete.  repetition_penalty > 0: RepetitionPenaltyLogitsProcessor over `history` (device
 // int64 [history_cap], *history_len entries; generated non-EOS ids are appended, as the reference's generated_token_ids list).
-extern "C" int aha_generate_greedy(aha_ctx* c, aha_stream* s, const int64_t* first_ids, int n_first, int max_new_tokens, int64_t eos_token_id,
-                                   float repetition_penalty, int64_t* history, int history_cap, int* history_len, int64_t* out_ids_host,
-                                   int* out_count, aha_hip_stream st_) {
+// Chunked use: a response can be produced in several calls - pass max_new_tokens = the chunk size, and continue with
+// first_ids = the last id of the previous chunk (n_first = 1, a device pointer) until an EOS arrives or the response limit is
+// reached; between chunks the caller may step other streams (the generation state is the stream's cache plus `history`).
+// on_token (optional): called with every new id as soon as it is host-visible (index = position in this call); a non-zero return
+// stops the generation after that token (the cache then holds exactly the tokens fed so far, as after an EOS stop).  The
+// callback may call aha_lm_step / aha_vit_encode for OTHER streams on the same HIP stream; it must not start another generation
+// on this context.  *out_count always reports the ids written to out_ids_host, also when the call fails part-way.
+extern "C" int aha_generate_greedy_cb(aha_ctx* c, aha_stream* s, const int64_t* first_ids, int n_first, int max_new_tokens, int64_t eos_token_id,
+                                      float repetition_penalty, int64_t* history, int history_cap, int* history_len, int64_t* out_ids_host,
+                                      int* out_count, aha_token_cb on_token, void* user, aha_hip_stream st_) {
+    if (out_count) *out_count = 0;
     if (!c || !s || !first_ids || n_first <= 0 || max_new_tokens <= 0 || !out_ids_host || !out_count) return AHA_E_INVAL;
     if (!c->embed) return fail(c, AHA_E_NOENT, "model.embed_tokens.weight was not loaded");
     if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
@@ -1642,34 +1652,53 @@ extern "C" int aha_generate_greedy(aha_ctx* c, aha_stream* s, const int64_t* fir
         if (hipHostMalloc((void**)&c->gen_pin, sizeof(long), hipHostMallocDefault) != hipSuccess) return fail(c, AHA_E_NOMEM, "hipHostMalloc failed");
         HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev, hipEventDisableTiming));
     }
-    if (c->gen_cap < max_new_tokens || (pen && c->gen_cap < history_cap)) {
-        const int cap = max_new_tokens > history_cap ? max_new_tokens : history_cap;
-        if ((rc = dalloc(c, &c->gen_out, (size_t)cap)) || (rc = dalloc(c, &c->gen_tmp, (size_t)cap))) return rc;
-        c->gen_cap = cap;
+    const int need = max_new_tokens > history_cap ? max_new_tokens : history_cap;
+    if (c->gen_cap < need) {
+        // geometric growth (a response history grows by one response per call), the replaced buffers are released: the work
+        // that used them was synchronised by the token polls of the call that enqueued it
+        int cap = c->gen_cap > 0 ? c->gen_cap : 1024;
+        while (cap < need) cap *= 2;
+        long* nout = nullptr; float* ntmp = nullptr;
+        if (hipMalloc((void**)&nout, (size_t)cap * sizeof(long)) != hipSuccess || hipMalloc((void**)&ntmp, (size_t)cap * sizeof(float)) != hipSuccess) {
+            if (nout) hipFree(nout);
+            return fail(c, AHA_E_NOMEM, "generation scratch allocation failed");
+        }
+        if (c->gen_out) { HIPCHK(c, hipStreamSynchronize(st)); hipFree(c->gen_out); hipFree(c->gen_tmp); }
+        c->gen_out = nout; c->gen_tmp = ntmp; c->gen_cap = cap;
     }
     if (pen) HIPCHK(c, hipMemcpyAsync(c->gen_nhist, history_len, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(c, aha_embed_gather((const long*)first_ids, n_first, c->embed, H, V, c->gen_emb, H, st));
     aha_stream* one[1] = {s};
-    int n = 0, T = n_first;
+    int T = n_first;
+    int& n = *out_count;                                      // kept current: an error return reports the ids already delivered
+#define GEN_CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(c, AHA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
     for (int i = 0; i < max_new_tokens; ++i) {
         if ((rc = aha_lm_step(c, one, 1, c->gen_emb, T, c->graph_scores + 3 * (AHA_MAX_B - 1), nullptr, nullptr, st_))) return rc;
         // lm_head on the last position -> fp32 logits (bf16-rounded, as a bf16 nn.Linear hands them on), penalty, argmax
         if ((rc = ws_gemm(c, -1, c->xn + (size_t)(T - 1) * H, T * H, 1, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, c->logits, V, st))) return rc;
-        if (pen) HIPCHK(c, aha_repetition_penalty(c->logits, V, (const long*)history, c->gen_nhist, repetition_penalty, c->gen_tmp, st));
-        HIPCHK(c, aha_argmax(c->logits, V, V, 1, c->gen_tok, st));
-        HIPCHK(c, aha_generation_bookkeep(c->gen_tok, (long)eos_token_id, (long*)history, c->gen_nhist, history_cap, pen ? 1 : 0, c->gen_out, i, st));
-        HIPCHK(c, aha_embed_gather(c->gen_tok, 1, c->embed, H, V, c->gen_emb, H, st));       // next step's input, no host in between
-        HIPCHK(c, hipMemcpyAsync(c->gen_pin, c->gen_tok, sizeof(long), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipEventRecord(c->gen_ev, st));
-        HIPCHK(c, hipEventSynchronize(c->gen_ev));
+        if (pen) GEN_CHK(aha_repetition_penalty(c->logits, V, (const long*)history, c->gen_nhist, repetition_penalty, c->gen_tmp, st));
+        GEN_CHK(aha_argmax(c->logits, V, V, 1, c->gen_tok, st));
+        GEN_CHK(aha_generation_bookkeep(c->gen_tok, (long)eos_token_id, (long*)history, c->gen_nhist, history_cap, pen ? 1 : 0, c->gen_out, i, st));
+        GEN_CHK(aha_embed_gather(c->gen_tok, 1, c->embed, H, V, c->gen_emb, H, st));         // next step's input, no host in between
+        GEN_CHK(hipMemcpyAsync(c->gen_pin, c->gen_tok, sizeof(long), hipMemcpyDeviceToHost, st));
+        GEN_CHK(hipEventRecord(c->gen_ev, st));
+        GEN_CHK(hipEventSynchronize(c->gen_ev));
         const long tok = *c->gen_pin;
         out_ids_host[n++] = tok;
         if (pen && tok != eos_token_id && *history_len < history_cap) ++*history_len;
         T = 1;
         if (tok == eos_token_id) break;
+        if (on_token && on_token(user, (int64_t)tok, i)) break;
     }
-    *out_count = n;
+#undef GEN_CHK
     return 0;
+}
+
+extern "C" int aha_generate_greedy(aha_ctx* c, aha_stream* s, const int64_t* first_ids, int n_first, int max_new_tokens, int64_t eos_token_id,
+                                   float repetition_penalty, int64_t* history, int history_cap, int* history_len, int64_t* out_ids_host,
+                                   int* out_count, aha_hip_stream st_) {
+    return aha_generate_greedy_cb(c, s, first_ids, n_first, max_new_tokens, eos_token_id, repetition_penalty, history, history_cap, history_len,
+                                  out_ids_host, out_count, nullptr, nullptr, st_);
 }
 
 extern "C" int aha_lm_last_step_work(aha_ctx* c, double* wb, double* kvb, double* fl) {

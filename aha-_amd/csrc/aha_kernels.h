@@ -106,11 +106,10 @@ hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo
 hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, hipStream_t st);   // sd_dev: DEVICE pointer
 hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, int T, bf16* out, int ldo, float scale, hipStream_t st);
-hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin, int layers, int Hkv, int D, hipStream_t st);
-hipError_t aha_cache_update_layer(const StreamStep* ss, int layer, int Hkv, int D, int T, const bf16* knew, const bf16* vnew, const bf16* rcos, const bf16* rsin, hipStream_t st);
+hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin, const bf16* cosb, const bf16* sinb, int layers, int Hkv, int D, hipStream_t st);
+hipError_t aha_cache_update_layer(const StreamStep* ss, int layer, int Hkv, int D, int T, const bf16* knew, const bf16* vnew, const bf16* rcos, const bf16* rsin, const bf16* cosb, const bf16* sinb, hipStream_t st);
 hipError_t aha_repetition_penalty(float* logits, int V, const long* hist, const int* n_hist, float penalty, float* tmp, hipStream_t st);
 hipError_t aha_generation_bookkeep(const long* tok, long eos, long* hist, int* n_hist, int cap, int use_hist, long* out_ids, int i, hipStream_t st);
-hipError_t aha_rerot_table(const bf16* cosb, const bf16* sinb, int D, int sink, int T, int rows, bf16* rc, bf16* rs, hipStream_t st);
 hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int count, const bf16* heads_w, int H, float* scores, float* raw, const int* poison, hipStream_t st);
 hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, const float* mean3, const float* std3, bf16* out, hipStream_t st);
 hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* pos, bf16* x, int n, int Np, int Dv, hipStream_t st);

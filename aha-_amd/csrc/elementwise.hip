@@ -315,24 +315,61 @@ static __device__ __forceinline__ void rerotate_store4(bf16* kp, bf16x4 x1, bf16
     *reinterpret_cast<bf16x4*>(kp + HALF) = o2;
 }
 
+// Re-rotation coefficients of kept key `row` (columns d..d+3), computed from the bf16 RoPE table exactly as
+// SinkCache._get_rerotation_cos_sin does (test/sink_cache.py:35-55) for T new tokens:
+//   original = table[sink+T + row], shifted = table[sink + row], both widened to fp32
+//   cos_r = oc*sc + os*ss ;  sin_r = -os*sc + oc*ss   -> bf16
+// torch evaluates each product and each sum as its own fp32 op, so contraction into FMAs is switched off (checked in the
+// ISA: v_mul_f32 / v_add_f32 only).  Same arithmetic as rerot_table_kernel below: a step that computes the coefficients
+// on the fly (no table registered) and one that reads a table give the same bits.  The RoPE table is L2-resident
+// (a few hundred KB), so the kernels stay bound by the K traffic.
+static __device__ __forceinline__ void rerot_coef4(const bf16* __restrict__ cosb, const bf16* __restrict__ sinb, int D, int sink, int T,
+                                                   int row, int d, bf16x4* c_out, bf16x4* s_out) {
+#pragma clang fp contract(off)
+    const long o0 = (long)(sink + T + row) * D + d, s0 = (long)(sink + row) * D + d;
+    const bf16x4 ocv = *reinterpret_cast<const bf16x4*>(cosb + o0), osv = *reinterpret_cast<const bf16x4*>(sinb + o0);
+    const bf16x4 scv = *reinterpret_cast<const bf16x4*>(cosb + s0), ssv = *reinterpret_cast<const bf16x4*>(sinb + s0);
+    bf16x4 c, s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float oc = bf2f(ocv[e]), os = bf2f(osv[e]), sc = bf2f(scv[e]), ss = bf2f(ssv[e]);
+        const float p0 = oc * sc, p1 = os * ss, p2 = (-os) * sc, p3 = oc * ss;
+        const float cc = p0 + p1, sn = p2 + p3;
+        c[e] = f2bf(rbf(cc));
+        s[e] = f2bf(rbf(sn));
+    }
+    *c_out = c;
+    *s_out = s;
+}
+
+// rcos_/rsin_ == nullptr: no (window, sink, T) table is registered - the coefficients come from the RoPE table (cosb/sinb) on
+// the fly, so the first evicting step of a stream allocates nothing and launches no table build.
 template <int D>
 __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __restrict__ sdp, unsigned stream_mask,
                                                             const void* __restrict__ rcos_, const void* __restrict__ rsin_,
+                                                            const void* __restrict__ cosb_, const void* __restrict__ sinb_,
                                                             int layers, int Hkv) {
     const bf16 *rcos = static_cast<const bf16*>(rcos_), *rsin = static_cast<const bf16*>(rsin_);
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
     const int b = blockIdx.z;
-    if (!((stream_mask >> b) & 1u)) return;                 // streams that share this launch's (W, sink, T) table
+    if (!((stream_mask >> b) & 1u)) return;                 // streams that share this launch's (W, sink) geometry
     const StreamStep ss = sdp->s[b];
     const int key = blockIdx.x * KPB + threadIdx.x / IPK;
     if (key >= ss.n_rerot) return;
     const int d = (threadIdx.x % IPK) * 4;
     const int slot = phys_slot(ss, ss.n_fixed + key);
     bf16* kp = ss.k_base + ((long)blockIdx.y * ss.cap + slot) * D + d;     // blockIdx.y = layer*Hkv + hk
-    const long trow = (long)(ss.rerot_row0 + key) * D;
     const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
-    const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d), s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
-    const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF), s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+    bf16x4 c1, s1, c2, s2;
+    if (rcos) {
+        const long trow = (long)(ss.rerot_row0 + key) * D;
+        c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d); s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
+        c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF); s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+    } else {
+        const bf16 *cosb = static_cast<const bf16*>(cosb_), *sinb = static_cast<const bf16*>(sinb_);
+        rerot_coef4(cosb, sinb, D, ss.n_fixed, sdp->T, ss.rerot_row0 + key, d, &c1, &s1);
+        rerot_coef4(cosb, sinb, D, ss.n_fixed, sdp->T, ss.rerot_row0 + key, d + HALF, &c2, &s2);
+    }
     rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
 }
 
@@ -343,7 +380,8 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
 template <int D>
 __global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, int layer, int Hkv, int T, const void* __restrict__ knew_,
                                                                  const void* __restrict__ vnew_, const void* __restrict__ rcos_,
-                                                                 const void* __restrict__ rsin_) {
+                                                                 const void* __restrict__ rsin_, const void* __restrict__ cosb_,
+                                                                 const void* __restrict__ sinb_) {
     const bf16 *knew = static_cast<const bf16*>(knew_), *vnew = static_cast<const bf16*>(vnew_);
     const bf16 *rcos = static_cast<const bf16*>(rcos_), *rsin = static_cast<const bf16*>(rsin_);
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
@@ -353,10 +391,17 @@ __global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, 
     const long lo = ((long)layer * Hkv + hk) * ss.cap;
     if (key < ss.n_rerot) {                                  // kept window keys: re-rotate in place
         bf16* kp = ss.k_base + (lo + phys_slot(ss, ss.n_fixed + key)) * D + d;
-        const long trow = (long)(ss.rerot_row0 + key) * D;
         const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
-        const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d), s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
-        const bf16x4 c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF), s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+        bf16x4 c1, s1, c2, s2;
+        if (rcos) {
+            const long trow = (long)(ss.rerot_row0 + key) * D;
+            c1 = *reinterpret_cast<const bf16x4*>(rcos + trow + d); s1 = *reinterpret_cast<const bf16x4*>(rsin + trow + d);
+            c2 = *reinterpret_cast<const bf16x4*>(rcos + trow + d + HALF); s2 = *reinterpret_cast<const bf16x4*>(rsin + trow + d + HALF);
+        } else {
+            const bf16 *cosb = static_cast<const bf16*>(cosb_), *sinb = static_cast<const bf16*>(sinb_);
+            rerot_coef4(cosb, sinb, D, ss.n_fixed, T, ss.rerot_row0 + key, d, &c1, &s1);
+            rerot_coef4(cosb, sinb, D, ss.n_fixed, T, ss.rerot_row0 + key, d + HALF, &c2, &s2);
+        }
         rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
     }
     if (key < ss.write_count && ss.write_base >= 0) {        // new tokens: append (distinct slots from the kept keys)
@@ -368,32 +413,6 @@ __global__ __launch_bounds__(256) void cache_update_layer_kernel(StreamStep ss, 
         *reinterpret_cast<bf16x4*>(ss.v_base + slot * D + d) = *reinterpret_cast<const bf16x4*>(vs);
         *reinterpret_cast<bf16x4*>(ss.v_base + slot * D + d + HALF) = *reinterpret_cast<const bf16x4*>(vs + HALF);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// SinkCache._get_rerotation_cos_sin (test/sink_cache.py:35-55) for T new tokens, built ON THE DEVICE from the bf16 RoPE
-// table so that no host table, upload or synchronisation sits in the first evicting step of a stream:
-//   original = table[sink+T + i], shifted = table[sink + i]   (i < W - sink - T), both widened to fp32
-//   cos_r = oc*sc + os*ss ;  sin_r = -os*sc + oc*ss   -> bf16
-// torch evaluates each product and each sum as its own fp32 op, so contraction into FMAs is switched off here
-// (checked in the ISA: v_mul_f32 / v_add_f32 only).
-// ---------------------------------------------------------------------------------------------
-// (kernel parameters that are raw bf16 pointers are passed as void*: rocprofv3's counter-collection mode crashed on kernels whose
-// mangled names carry the bf16 type outside a struct - it could not demangle them)
-__global__ void rerot_table_kernel(const void* __restrict__ cosb_, const void* __restrict__ sinb_, int D, int sink, int T, int rows,
-                                   void* __restrict__ rc_, void* __restrict__ rs_) {
-#pragma clang fp contract(off)
-    const bf16 *cosb = static_cast<const bf16*>(cosb_), *sinb = static_cast<const bf16*>(sinb_);
-    bf16 *rc = static_cast<bf16*>(rc_), *rs = static_cast<bf16*>(rs_);
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long)rows * D) return;
-    const int i = (int)(gid / D), d = (int)(gid % D);
-    const float oc = bf2f(cosb[(long)(sink + T + i) * D + d]), os = bf2f(sinb[(long)(sink + T + i) * D + d]);
-    const float sc = bf2f(cosb[(long)(sink + i) * D + d]), ss = bf2f(sinb[(long)(sink + i) * D + d]);
-    const float p0 = oc * sc, p1 = os * ss, p2 = (-os) * sc, p3 = oc * ss;
-    const float c = p0 + p1, s = p2 + p3;
-    rc[gid] = f2bf(rbf(c));
-    rs[gid] = f2bf(rbf(s));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -692,33 +711,27 @@ hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd
     return hipGetLastError();
 }
 hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin,
-                             int layers, int Hkv, int D, hipStream_t st) {
+                             const bf16* cosb, const bf16* sinb, int layers, int Hkv, int D, hipStream_t st) {
     if (nmax == 0 || stream_mask == 0) return hipSuccess;
     if (D == 64) {
         const int kpb = 256 / (64 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers, Hkv);
     } else if (D == 128) {
         const int kpb = 256 / (128 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers, Hkv);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-hipError_t aha_rerot_table(const bf16* cosb, const bf16* sinb, int D, int sink, int T, int rows, bf16* rc, bf16* rs, hipStream_t st) {
-    const long total = (long)rows * D;
-    if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rerot_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cosb, sinb, D, sink, T, rows, rc, rs);
-    return hipGetLastError();
-}
 hipError_t aha_cache_update_layer(const StreamStep* ss, int layer, int Hkv, int D, int T, const bf16* knew, const bf16* vnew,
-                                   const bf16* rcos, const bf16* rsin, hipStream_t st) {
+                                   const bf16* rcos, const bf16* rsin, const bf16* cosb, const bf16* sinb, hipStream_t st) {
     const int n = ss->n_rerot > ss->write_count ? ss->n_rerot : ss->write_count;
     if (n <= 0) return hipSuccess;
     if (D == 64) {
         const int kpb = 256 / (64 / 8);
-        hipLaunchKernelGGL((cache_update_layer_kernel<64>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin);
+        hipLaunchKernelGGL((cache_update_layer_kernel<64>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin, cosb, sinb);
     } else if (D == 128) {
         const int kpb = 256 / (128 / 8);
-        hipLaunchKernelGGL((cache_update_layer_kernel<128>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin);
+        hipLaunchKernelGGL((cache_update_layer_kernel<128>), dim3(ceil_div(n, kpb), Hkv), dim3(256), 0, st, *ss, layer, Hkv, T, knew, vnew, rcos, rsin, cosb, sinb);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }

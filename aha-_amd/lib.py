@@ -67,6 +67,7 @@ SYMBOLS = [
     ("aha_version", C.c_char_p, []),
     ("aha_lm_logits_all", _I, [_P, _P, _P]),
     ("aha_generate_greedy", _I, [_P, _P, _P, _I, _I, C.c_int64, _F, _P, _I, C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I), _P]),
+    ("aha_generate_greedy_cb", _I, [_P, _P, _P, _I, _I, C.c_int64, _F, _P, _I, C.POINTER(_I), C.POINTER(C.c_int64), C.POINTER(_I), _P, _P, _P]),
     ("aha_linear_create", _I, [_P, _P, _P, _I, _I, C.POINTER(_P), _P]),
     ("aha_linear_destroy", None, [_P]),
     ("aha_linear_split_k", _I, [_P, _P, _I]),
@@ -89,6 +90,7 @@ SYMBOLS = [
 EPI_SPLITK_F32, EPI_BF16, EPI_SWIGLU, EPI_F32 = 0, 1, 2, 3
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_QUICK_GELU = 0, 1, 2, 3
 COMM_ID_BYTES = 128
+TOKEN_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)      # aha_token_cb
 
 
 def load(path: str = LIB_PATH) -> C.CDLL:

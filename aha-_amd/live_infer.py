@@ -2,7 +2,7 @@
 
   LiveInferForBenchmark  <- test/inference.py:38-348
   LiveInferForDemo       <- test/live_infer_for_video.py:80-228
-  round_numbers          <- test/inference.py:359-375
+  round_numbers          <- test/inference.py:359-375 (same results, own formulation)
 
 Same method names, argument meaning, attributes and `debug_data_list` schema
 (`{time, informative_score, relevance_score, uncertainty_score}`), so code written against the
@@ -30,23 +30,29 @@ from .runtime import Runtime, Stream
 from .tokenization import SyntheticChatTokenizer
 
 
-def truncate_sig(x, sig=3):
-    if x == 0:
-        return 0
-    return float(f"{x:.{sig}g}")
-
-
 def round_numbers(data, n):
+    """Rounding of the debug rows (same results as the reference helper, test/inference.py:359-375): floats are rounded
+    to n decimals, except magnitudes <= 10**-n, which keep n significant digits instead of collapsing to 0 (an exact
+    zero becomes the int 0); lists and dicts are walked, everything else passes through."""
+    if isinstance(data, dict):
+        return {key: round_numbers(val, n) for key, val in data.items()}
     if isinstance(data, list):
-        return [round_numbers(d, n) for d in data]
-    elif isinstance(data, dict):
-        return {k: round_numbers(v, n) for k, v in data.items()}
-    elif isinstance(data, float):
-        if abs(data) <= 10 ** (-n):
-            return truncate_sig(data, n)
-        else:
-            return round(data, n)
-    return data
+        return [round_numbers(item, n) for item in data]
+    if not isinstance(data, float):
+        return data
+    if abs(data) > 10.0 ** (-n):
+        return round(data, n)
+    return float(format(data, f".{n}g")) if data else 0
+
+
+def truncate_sig(x, sig=3):
+    """`sig` significant digits of x (kept for callers of the reference's helper name)."""
+    return float(format(x, f".{sig}g")) if x else 0
+
+
+# per-video driver state, re-created by reset() (attribute names are the reference's: test/inference.py:112-130)
+_STREAM_STATE = dict(video_time=0, frame_idx=0, last_role="system", video_tensor=None, first_query_processed=False,
+                     init_vision_time=False, num_frames_no_reply=0, stream_end_score_sum=0, consecutive_n_frames=0)
 
 
 class LiveInferForBenchmark:
@@ -70,33 +76,24 @@ class LiveInferForBenchmark:
         self.tokenizer = tokenizer or SyntheticChatTokenizer(self.cfg.lm.vocab_size)
         self._window_length, self._num_sink_tokens, self._attn_semantics = window_length, num_sink_tokens, attn_semantics
 
-        # visual
+        # the reference's driver attributes, by name (test/inference.py:39-99): geometry from the model config, the trigger and
+        # waiting knobs straight from `args`
         self.hidden_size = self.cfg.lm.hidden_size
+        self.frame_resolution, self.frame_num_tokens = self.cfg.frame_resolution, self.cfg.frame_num_tokens
         if args.frame_fps > 0:
             self.set_fps(args.frame_fps)
-        self.frame_resolution = self.cfg.frame_resolution
-        self.frame_num_tokens = self.cfg.frame_num_tokens
-
-        self.uncertainty_wait_threshold = args.uncertainty_wait_threshold
-        self.max_wait_frames = args.max_wait_frames
-
-        # generation
-        self.system_prompt = args.system_prompt
-        self.max_new_tokens = 200                                  # inplace_output_ids is [1,200] (test/inference.py:73)
-        self.stream_end_prob_threshold = args.stream_end_prob_threshold
-        self.response_min_interval_frames = args.response_min_interval_frames
-        self.threshold_z = args.threshold_z
-        self.first_n_frames_no_generate = args.first_n_frames_no_generate
-        self.running_list_length = args.running_list_length
-        self.stream_end_score_sum_threshold = args.stream_end_score_sum_threshold
+        for knob in ("uncertainty_wait_threshold", "max_wait_frames", "system_prompt", "stream_end_prob_threshold",
+                     "response_min_interval_frames", "threshold_z", "first_n_frames_no_generate", "running_list_length",
+                     "stream_end_score_sum_threshold", "consecutive_n_frames_threshold"):
+            setattr(self, knob, getattr(args, knob))
         self.score_heads = args.score_heads.split(",")
-        self.consecutive_n_frames_threshold = args.consecutive_n_frames_threshold
-        n_set = (int(self.threshold_z is not None) + int(self.stream_end_prob_threshold is not None)
-                 + int(self.stream_end_score_sum_threshold is not None))
-        if n_set != 1:
-            raise ValueError(
-                "only one of --stream_end_prob_threshold, --threshold_z and --stream_end_score_sum_threshold can be set. "
-                f"However, they are: {self.stream_end_prob_threshold}, {self.threshold_z}, {self.stream_end_score_sum_threshold}")
+        self.max_new_tokens = 200                                  # the reference's output buffer is [1,200] (test/inference.py:73)
+        triggers = dict(stream_end_prob_threshold=self.stream_end_prob_threshold, threshold_z=self.threshold_z,
+                        stream_end_score_sum_threshold=self.stream_end_score_sum_threshold)
+        if sum(v is not None for v in triggers.values()) != 1:
+            raise ValueError("only one of --stream_end_prob_threshold, --threshold_z and --stream_end_score_sum_threshold can be set. "
+                             f"However, they are: {triggers['stream_end_prob_threshold']}, {triggers['threshold_z']}, "
+                             f"{triggers['stream_end_score_sum_threshold']}")
         if self.threshold_z is not None and self.first_n_frames_no_generate is None:
             raise ValueError("--first_n_frames_no_generate must be set when --threshold_z is set")
         self.remove_assistant_turns = args.remove_assistant_turns
@@ -113,33 +110,22 @@ class LiveInferForBenchmark:
 
     # ---- test/inference.py:101-110 ---------------------------------------------------------------
     def set_fps(self, fps=None, frame_interval=None):
-        assert fps is not None or frame_interval is not None
-        assert not (fps is not None and frame_interval is not None)
-        if fps is not None:
-            self.frame_fps = fps
-            self.frame_interval = 1 / self.frame_fps
-        else:
-            self.frame_interval = frame_interval
-            self.frame_fps = 1 / self.frame_interval
+        """Exactly one of `fps` / `frame_interval` (seconds); the other is derived."""
+        assert (fps is None) != (frame_interval is None)
+        self.frame_fps = fps if fps is not None else 1 / frame_interval
+        self.frame_interval = frame_interval if frame_interval is not None else 1 / fps
 
     # ---- test/inference.py:112-130 ---------------------------------------------------------------
     def reset(self):
-        self.query_queue = collections.deque()
-        self.frame_embeds_queue = collections.deque()
-        self.video_time = 0
-        self.frame_idx = 0
-        self.last_role = "system"
-        self.video_tensor = None
-        self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        for name, value in _STREAM_STATE.items():
+            setattr(self, name, value)
+        self.query_queue, self.frame_embeds_queue = collections.deque(), collections.deque()
+        self.debug_data_list, self.generated_token_ids, self.stream_end_prob_list = [], [], []
+        self.last_ids = self._no_ids()
         self._init_cache(self._window_length, self._num_sink_tokens)
-        self.first_query_processed = False
-        self.debug_data_list = list()
-        self.generated_token_ids = list()
-        self.init_vision_time = False
-        self.num_frames_no_reply = 0
-        self.stream_end_prob_list = list()
-        self.stream_end_score_sum = 0
-        self.consecutive_n_frames = 0
+
+    def _no_ids(self):
+        return torch.zeros((1, 0), device=self.device, dtype=torch.long)
 
     # ---- test/inference.py:133-155 ---------------------------------------------------------------
     def _init_cache(self, window_length=2048, num_sink_tokens=32, instruction_ids=None):
@@ -197,7 +183,7 @@ class LiveInferForBenchmark:
         elif self.last_role == "assistant" and not self.remove_assistant_turns:
             self.last_ids = torch.cat([self.last_ids, self._added_stream_prompt_ids], dim=1)
         else:
-            self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+            self.last_ids = self._no_ids()
         inputs_embeds = torch.cat([
             self.rt.embed_tokens(self.last_ids).view(1, -1, self.hidden_size),
             frame_embeds.view(1, -1, self.hidden_size)], dim=1)
@@ -222,19 +208,44 @@ class LiveInferForBenchmark:
         self.last_role = "user"
 
     # ---- models/modeling_live.py:64-90 (fast_greedy_generate) + test/inference.py:264-281 ----------
+    generation_chunk: Optional[int] = None        # tokens per aha_generate_greedy call (None: the whole response in one call)
+    between_chunks = None                         # callable run between chunks, e.g. to step other streams of a server
+
     def _generate_response(self):
         """fast_greedy_generate runs inside the runtime (aha_generate_greedy): argmax -> embedding -> next single-token step
-        stay on the device, the host only reads back each 8-byte token id to stop at EOS."""
+        stay on the device, the host only reads back each 8-byte token id to stop at EOS.  With `generation_chunk` set the
+        response is produced in chunks of that many tokens (same ids), `between_chunks()` running in between."""
         self.last_ids = self._added_stream_generation_ids
+        chunked = dict(chunk=self.generation_chunk, between_chunks=self.between_chunks) if self.generation_chunk else {}
         output_ids = self.rt.generate_greedy(self.past_key_values, self.last_ids, self.max_new_tokens, self.eos_token_id,
-                                             self.repetition_penalty, self.generated_token_ids)
-        if not self.remove_assistant_turns:
-            self.last_ids = torch.tensor([[output_ids[-1]]], device=self.device)
-        else:
-            self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
-        response = self.tokenizer.decode(output_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+                                             self.repetition_penalty, self.generated_token_ids, **chunked)
+        self.last_ids = self._no_ids() if self.remove_assistant_turns else torch.tensor([[output_ids[-1]]], device=self.device)
         self.num_frames_no_reply = 0
         self.last_role = "assistant"
+        return self.tokenizer.decode(output_ids, skip_special_tokens=True, clean_up_tokenization_spaces=True)
+
+    # ---- the response trigger, one rule for both drivers (test/inference.py:311-326, test/live_infer_for_video.py:151-165) ------
+    def _response_due(self, video_scores) -> bool:
+        """Fold one frame's scores into the running statistics and say whether a response is due: the sum over `score_heads`
+        either exceeds the per-frame threshold, or pushes the running sum over its threshold (which then restarts at 0)."""
+        frame_score = sum(v for k, v in video_scores.items() if k in self.score_heads)
+        self.stream_end_prob_list.append(frame_score)
+        keep = self.running_list_length
+        if isinstance(keep, int) and keep > 0:
+            del self.stream_end_prob_list[:-keep]
+        self.stream_end_score_sum += frame_score
+        due = False
+        if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
+            self.stream_end_score_sum = 0
+            due = True
+        if self.stream_end_prob_threshold is not None and frame_score > self.stream_end_prob_threshold:
+            due = True
+        return due
+
+    def _respond(self):
+        response = self._generate_response()
+        self.num_frames_no_reply = 0
+        self.consecutive_n_frames = 0
         return response
 
     # ---- test/inference.py:283-335 ---------------------------------------------------------------
@@ -261,54 +272,42 @@ class LiveInferForBenchmark:
         self.frame_idx += g
         self.num_frames_no_reply += g
         self.last_role = "stream"
-        self.last_ids = torch.zeros((1, 0), device=self.device, dtype=torch.long)
+        self.last_ids = self._no_ids()
         return scores
+
+    def _can_batch_static(self, frames_per_step: int) -> bool:
+        if not (frames_per_step > 1 and self.alt_cache == "static" and not self.sink_cache and len(self.frame_embeds_queue) > 1):
+            return False
+        frozen = self.init_vision_time and self.last_role == "stream" and self.past_key_values.get_seq_length() > 0
+        horizon = self.video_time + (frames_per_step - 1) / self.frame_fps
+        return frozen and not (self.query_queue and self.query_queue[0][0] <= horizon)
 
     @torch.no_grad()
     def inference(self, verbose=False, total=None, frames_per_step: int = 1, static_last_token_only: bool = False):
-        model_response_list = [{"time": q[0], "content": q[1], "role": "user"} for q in self.query_queue]
+        """The benchmark loop (test/inference.py:283-348): per queued frame - a user query that has become due is encoded
+        first, the frame is scored, the debug row is recorded, a response is generated when the trigger fires, and the clock
+        advances by one frame interval.  Returns the conversation (queries + responses) ordered by time."""
+        turns = [{"time": t, "content": q, "role": "user"} for t, q in self.query_queue]
         pending = collections.deque()        # scores already computed by a static batched step
         while self.frame_embeds_queue or pending:
-            # 1. check if a user query is at current time
             if self.query_queue and self.video_time >= self.query_queue[0][0]:
                 self._encode_query()
-            # 2. input a frame, and update the scores list
-            can_batch = (frames_per_step > 1 and self.alt_cache == "static" and not self.sink_cache and self.init_vision_time
-                         and self.last_role == "stream" and self.past_key_values.get_seq_length() > 0
-                         and not (self.query_queue and self.query_queue[0][0] <= self.video_time + (frames_per_step - 1) / self.frame_fps))
-            if not pending and can_batch and len(self.frame_embeds_queue) > 1:
+            if not pending and self._can_batch_static(frames_per_step):
                 pending.extend(self._encode_frames_static_batched(frames_per_step, static_last_token_only))
             if pending:
-                s = pending.popleft()
-                video_scores, uncertainty_score = {"informative_score": s[0], "relevance_score": s[1]}, s[2]
+                info, rel, uncertainty_score = pending.popleft()
+                video_scores = {"informative_score": info, "relevance_score": rel}
             else:
                 video_scores, uncertainty_score = self._encode_frame()
             self.debug_data_list.append(dict(time=self.video_time, **video_scores, uncertainty_score=uncertainty_score))
-            # 3. check the scores, if need to generate a response
-            need_response = False
-            stream_end_score = sum([v for k, v in video_scores.items() if k in self.score_heads])
-            self.stream_end_prob_list.append(stream_end_score)
-            self.stream_end_score_sum += stream_end_score
-            if isinstance(self.running_list_length, int) and self.running_list_length > 0:
-                self.stream_end_prob_list = self.stream_end_prob_list[-self.running_list_length:]
-            if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
-                need_response = True
-                self.stream_end_score_sum = 0
-            if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
-                need_response = True
-            # 4. record the responses
-            if need_response and pending:
-                raise RuntimeError("a response was triggered inside a static batched step: use frames_per_step=1 with response thresholds")
-            if need_response:
-                response = self._generate_response()
-                model_response_list.append({"time": self.video_time, "content": response, "role": "assistant"})
-                self.num_frames_no_reply = 0
-                self.consecutive_n_frames = 0
-            # 5. update the video time
+            if self._response_due(video_scores):
+                if pending:
+                    raise RuntimeError("a response was triggered inside a static batched step: use frames_per_step=1 with response thresholds")
+                turns.append({"time": self.video_time, "content": self._respond(), "role": "assistant"})
             self.video_time += 1 / self.frame_fps
             if verbose and self.frame_idx % 50 == 0:
                 print(f"frame {self.frame_idx}" + (f"/{total}" if total else "") + f" {self.video_time:.2f}s", flush=True)
-        return sorted(model_response_list, key=lambda x: x["time"])
+        return sorted(turns, key=lambda x: x["time"])
 
 
 def sample_frame_indices(input_fps, frame_count, output_fps, max_num_frames=None, floor_total=False):
@@ -367,26 +366,8 @@ class LiveInferForDemo(LiveInferForBenchmark):
     # ---- test/live_infer_for_video.py:135-176 ----------------------------------------------------------
     def input_one_frame(self):
         video_scores, uncertainty_scores = self._encode_frame()
-        ret = dict(frame_idx=self.frame_idx, time=round(self.video_time, 1), uncertainty_score=uncertainty_scores,
-                   **video_scores)
-        need_response = False
-        stream_end_score = sum([v for k, v in video_scores.items() if k in self.score_heads])
-        self.stream_end_prob_list.append(stream_end_score)
-        self.stream_end_score_sum += stream_end_score
-        if isinstance(self.running_list_length, int) and self.running_list_length > 0:
-            self.stream_end_prob_list = self.stream_end_prob_list[-self.running_list_length:]
-        if self.stream_end_score_sum_threshold is not None and self.stream_end_score_sum > self.stream_end_score_sum_threshold:
-            need_response = True
-            self.stream_end_score_sum = 0
-        if self.stream_end_prob_threshold is not None and stream_end_score > self.stream_end_prob_threshold:
-            need_response = True
-        if need_response:
-            response = self._generate_response()
-            self.num_frames_no_reply = 0
-            self.consecutive_n_frames = 0
-        else:
-            response = None
-        ret["response"] = response
+        ret = dict(frame_idx=self.frame_idx, time=round(self.video_time, 1), uncertainty_score=uncertainty_scores, **video_scores)
+        ret["response"] = self._respond() if self._response_due(video_scores) else None
         self.video_time += 1 / self.frame_fps
         return ret
 

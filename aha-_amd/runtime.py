@@ -304,12 +304,15 @@ class Runtime:
         return lg.view(B, T, -1)
 
     def generate_greedy(self, stream: Stream, first_ids: torch.Tensor, max_new_tokens: int, eos_token_id: int,
-                        repetition_penalty: Optional[float] = None, generated_token_ids: Optional[list] = None) -> List[int]:
+                        repetition_penalty: Optional[float] = None, generated_token_ids: Optional[list] = None, *,
+                        chunk: Optional[int] = None, between_chunks=None, on_token=None) -> List[int]:
         """fast_greedy_generate (models/modeling_live.py:64-90): returns the new token ids (the last one is EOS unless the
-        limit was hit) and, with a repetition penalty, appends the non-EOS ones to `generated_token_ids` like the reference."""
+        limit was hit) and, with a repetition penalty, appends the non-EOS ones to `generated_token_ids` like the reference.
+        chunk: produce the response `chunk` tokens per aha_generate_greedy call (same ids as one call), running
+        `between_chunks()` in between - other streams can step while a response is being written.
+        on_token(token_id, index) -> truthy stops after that token (aha_generate_greedy_cb); it is called on the host as soon
+        as the id is visible and may enqueue steps of other streams."""
         ids = first_ids.to(device=self.device, dtype=torch.long).contiguous().view(-1)
-        out = (C.c_int64 * max_new_tokens)()
-        n = C.c_int(0)
         pen = float(repetition_penalty) if repetition_penalty is not None else 0.0
         hist, hlen = None, C.c_int(0)
         if pen > 0:
@@ -318,10 +321,34 @@ class Runtime:
             if prev:
                 hist[:len(prev)] = torch.tensor(prev, dtype=torch.long)
             hlen = C.c_int(len(prev))
-        self._chk(self.lib.aha_generate_greedy(self.ctx, stream.handle, ids.data_ptr(), ids.numel(), max_new_tokens, int(eos_token_id), pen,
-                                               hist.data_ptr() if hist is not None else None, hist.numel() if hist is not None else 0,
-                                               C.byref(hlen), out, C.byref(n), _cur_stream()))
-        toks = [int(out[i]) for i in range(n.value)]
+        stopped = []
+        cb = None
+        if on_token is not None:
+            def _cb(_user, tok, idx, _base=[0]):
+                stop = 1 if on_token(int(tok), _base[0] + idx) else 0
+                if stop:
+                    stopped.append(True)
+                return stop
+            cb = _l.TOKEN_CB(_cb)
+        toks: List[int] = []
+        step = max_new_tokens if not chunk or chunk <= 0 else int(chunk)
+        while len(toks) < max_new_tokens:
+            k = min(step, max_new_tokens - len(toks))
+            out = (C.c_int64 * k)()
+            n = C.c_int(0)
+            if cb is not None:
+                _cb.__defaults__[0][0] = len(toks)
+            self._chk(self.lib.aha_generate_greedy_cb(
+                self.ctx, stream.handle, ids.data_ptr(), ids.numel(), k, int(eos_token_id), pen,
+                hist.data_ptr() if hist is not None else None, hist.numel() if hist is not None else 0, C.byref(hlen), out, C.byref(n),
+                C.cast(cb, C.c_void_p) if cb is not None else None, None, _cur_stream()))
+            toks.extend(int(out[i]) for i in range(n.value))
+            if n.value < k or toks[-1] == eos_token_id or stopped:
+                break
+            if len(toks) < max_new_tokens:
+                ids = torch.tensor([toks[-1]], dtype=torch.long, device=self.device)    # the next chunk continues from the last id
+                if between_chunks is not None:
+                    between_chunks()
         if pen > 0 and generated_token_ids is not None:
             generated_token_ids.extend(t for t in toks if t != eos_token_id)
         return toks

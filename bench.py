@@ -105,17 +105,21 @@ def cu_masked_stream(first_cu, n_cus, total_cus):
     return torch.cuda.ExternalStream(st.value)
 
 
-def pmc_traffic(kernel_prefix, steady=False):
-    """HBM bytes per launch of a kernel from the newest committed PMC summary (counters cannot be collected from
-    inside the process being measured).  steady: the largest dispatch (kernels whose work grows with the cache)."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+def pmc_traffic(kernel_prefix, workload):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (counters cannot be collected from inside the
+    process being measured) - only from a counter run of the SAME workload as the timed one: a summary row carries the
+    workload it was collected on ("static_1stream", "static_8stream", "sink_1stream_steady", "sink_8stream_steady"); rows of any
+    other workload, or a summary that does not say, give None."""
+    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
-            for k in d["kernels"]:
-                if kernel_prefix in k["kernel"]:
-                    return k.get("hbm_bytes_per_launch_max" if steady else "hbm_bytes_per_launch", k["hbm_bytes_per_launch"]), name
         except Exception:
-            pass
+            continue
+        # the round-2 file was collected on static-cache runs only (tools/pmc_round.sh of that round), 1 and 8 streams merged per kernel
+        for k in d["kernels"]:
+            wl = k.get("workload", d.get("workload", "static_1stream+static_8stream"))
+            if kernel_prefix in k["kernel"] and workload in wl.split("+"):
+                return k["hbm_bytes_per_launch"], name
     return None, None
 
 
@@ -237,12 +241,12 @@ def timed_kind(rt, wl, emb, kind, n_steps=4, skip=1):
     return ms, n, by
 
 
-def roofline_hbm(kernel, ms, n, by, traffic_prefix=None, steady=False):
+def roofline_hbm(kernel, ms, n, by, traffic_prefix=None, workload=None):
     ach = (by / n) / ((ms / n) * 1e-3) / 1e9 if n and ms > 0 else None
-    traffic, src = pmc_traffic(traffic_prefix, steady) if traffic_prefix else (None, None)
+    traffic, src = pmc_traffic(traffic_prefix, workload) if traffic_prefix and workload else (None, None)
     return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS if ach else None, "avg_launch_us": ms / n * 1e3 if n else None, "launches_timed": n,
-            "algorithmic_bytes_per_launch": by / n if n else None, "traffic": traffic,
+            "algorithmic_bytes_per_launch": by / n if n else None, "traffic": traffic, "traffic_workload": workload if traffic is not None else None,
             "traffic_source": (f"profiles/{src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction 2*FETCH+WRITE)" if src else None)}
 
 
@@ -436,7 +440,7 @@ def main():
 
     if rank == 0:
         total_frames = F * B * world * a.steps
-        rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,")
+        rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,", "static_1stream")
         out = {
             "metric": "frames/sec scored (whole node)", "value": total_frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -570,9 +574,9 @@ def sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_st
     out = {"workload": f"1 stream, SinkCache W=2048 sink=32 at steady state (evicting every step), {F} frames/step",
            "frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3,
            "roofline_attention": roofline_hbm("attn_fwd_kernel<128,true> + attn_combine_kernel (one layer: 2,048 keys x 4 KV heads, K and V read once)",
-                                              a_ms, a_n, a_by, "attn_fwd_kernel<128, true>", steady=True),
+                                              a_ms, a_n, a_by, "attn_fwd_kernel<128, true>", "sink_1stream_steady"),
            "roofline_rerotation": roofline_hbm("sink_rerotate_kernel<128> (all 28 layers: kept keys read + written in place)", r_ms, r_n, r_by,
-                                               "sink_rerotate_kernel", steady=True)}
+                                               "sink_rerotate_kernel", "sink_1stream_steady")}
     wl.close()
     return out
 
@@ -599,7 +603,8 @@ def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, 
     M = B2 * tf
     flops = 2.0 * M * (2 * cfg.lm.intermediate_size) * cfg.lm.hidden_size
     tf_s = flops / ((g_ms / g_n) * 1e-3) / 1e12 if g_n else None
-    rl = roofline_hbm("gemm_wl_bal18_kernel (gate/up + SwiGLU at M = 288 rows)", g_ms, g_n, g_by, "gemm_wl_bal18_kernel")
+    # the GEMM does not read the cache: its counter row from the 8-stream static run is the same launch (same M, same weights)
+    rl = roofline_hbm("gemm_wl_bal18_kernel (gate/up + SwiGLU at M = 288 rows)", g_ms, g_n, g_by, "gemm_wl_bal18_kernel", "static_8stream")
     rl.update({"mfma_achieved_TFLOPs": tf_s, "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS, "mfma_frac": tf_s / MFMA_PEAK_TFLOPS if tf_s else None,
                "flops_per_launch": flops, "note": "arithmetic intensity ~288 flop/B sits on the ridge (312): both fractions are reported"})
     out = {"workload": f"{B2} streams/GPU, SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step (M = {M} rows per LM step)",

@@ -11,14 +11,17 @@
  * the caller (bf16 unless stated); KV caches are owned by aha_stream.  The per-frame calls
  * (aha_frame_ingest, aha_vit_encode*, aha_embed_tokens, aha_lm_step, aha_lm_heads_all,
  * aha_lm_last_hidden_all, aha_lm_logits*, aha_generate_greedy, aha_cache_update) enqueue work on the
- * given hipStream_t and never synchronise with the host, first use included (coefficient and
- * re-rotation tables are built / uploaded asynchronously on that stream).  Set-up and tear-down calls
+ * given hipStream_t and never synchronise with the host, first use included (frame-ingest coefficient
+ * tables are uploaded asynchronously on that stream; SinkCache re-rotation coefficients are computed
+ * inside the kernel).  Set-up and tear-down calls
  * (aha_ctx_create / _load_weights / _set_rope_table / _set_rerotation_table / _destroy,
  * aha_stream_open / _destroy) may block.  One aha_ctx per process / GPU; not thread-safe.  The LM and
  * vision workspaces belong to the context: a call submitted on a different HIP stream than the
  * previous call of the same family is ordered behind it with an event (serialised, never racing).
- * If a per-frame call fails, the streams' bookkeeping (length, ring head, seen tokens) is restored
- * to what it was before the call.
+ * If a per-frame call fails before any cache-changing work was enqueued, the streams' bookkeeping
+ * (length, ring head, seen tokens) is restored to what it was before the call and the call may be
+ * retried; if it fails after an evicting step's in-place re-rotation / ring overwrite was enqueued,
+ * the streams are marked unusable instead (every later step returns -22) until aha_stream_reset.
  */
 #ifndef AHA_AMD_H
 #define AHA_AMD_H
@@ -86,9 +89,9 @@ int aha_ctx_load_weights(aha_ctx* ctx, const aha_tensor_view* tensors, size_t n,
  * transformers modeling_qwen2.py:87-102); copied. */
 int aha_ctx_set_rope_table(aha_ctx* ctx, const void* cos_bf16, const void* sin_bf16, int n_pos, aha_hip_stream st);
 /* SinkCache._get_rerotation_cos_sin table for new-token count T (test/sink_cache.py:35-55),
- * bf16 [window - n_sink - T][head_dim]; copied, keyed by (window, n_sink, T).  OPTIONAL: aha_lm_step
- * builds the identical table on the device from the RoPE table (asynchronously, on the step's stream)
- * the first time a combination evicts; this entry point lets a caller supply its own instead. */
+ * bf16 [window - n_sink - T][head_dim]; copied, keyed by (window, n_sink, T).  OPTIONAL: without one the
+ * re-rotation kernel computes the identical coefficients from the RoPE table on the fly (nothing is
+ * allocated or built inside a per-frame call); this entry point lets a caller supply its own instead. */
 int aha_ctx_set_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T, const void* cos_bf16,
                                  const void* sin_bf16, aha_hip_stream st);
 int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
@@ -203,10 +206,20 @@ int aha_lm_logits_all(aha_ctx* ctx, float* logits, aha_hip_stream st);
 /* ---- response generation: fast_greedy_generate (models/modeling_live.py:64-90) as called by _generate_response
  * (test/inference.py:264-281).  Greedy single-token steps from the `first_ids` prompt (device int64 [n_first]) against the
  * stream's cache, at most max_new_tokens, stopping after eos_token_id.  argmax -> embedding -> next step stay on the device;
- * the host polls the 8-byte token id behind each step to stop exactly at EOS, so this call BLOCKS until the response is done.
+ * the host polls the 8-byte token id behind each step to stop exactly at EOS, so a call blocks for the tokens it produces.
+ * A response need not be one call: pass max_new_tokens = a chunk size and continue with first_ids = the chunk's last id
+ * (n_first = 1) until EOS or the response limit - between chunks other streams may step (a multi-stream server is not
+ * stalled by one stream's response).  aha_generate_greedy_cb additionally hands every new id to `on_token` as soon as it is
+ * host-visible; a non-zero return stops after that token.  The callback may enqueue steps of OTHER streams on the same HIP
+ * stream; it must not start another generation on this context.
  * repetition_penalty > 0 applies RepetitionPenaltyLogitsProcessor over `history` (device int64 [history_cap] holding
  * *history_len ids; generated non-EOS ids are appended like the reference's generated_token_ids list) - <= 0 disables it.
- * out_ids_host: host int64 [max_new_tokens]; *out_count: tokens produced (the last one is EOS unless the limit was hit). */
+ * out_ids_host: host int64 [max_new_tokens]; *out_count: tokens produced (the last one is EOS unless the limit was hit or the
+ * callback stopped it) - also set when the call fails part-way (the cache has advanced by the tokens fed so far). */
+typedef int (*aha_token_cb)(void* user, int64_t token_id, int index);
+int aha_generate_greedy_cb(aha_ctx* ctx, aha_stream* s, const int64_t* first_ids_dev, int n_first, int max_new_tokens,
+                           int64_t eos_token_id, float repetition_penalty, int64_t* history_dev, int history_cap, int* history_len,
+                           int64_t* out_ids_host, int* out_count, aha_token_cb on_token, void* user, aha_hip_stream st);
 int aha_generate_greedy(aha_ctx* ctx, aha_stream* s, const int64_t* first_ids_dev, int n_first, int max_new_tokens,
                         int64_t eos_token_id, float repetition_penalty, int64_t* history_dev, int history_cap, int* history_len,
                         int64_t* out_ids_host, int* out_count, aha_hip_stream st);

@@ -65,8 +65,21 @@ class OracleBackedRuntime:
         lg = torch.cat([o["logits"][:, -1] for o in self._last], 0)
         return (lg if want_logits else None), lg.argmax(-1)
 
-    def generate_greedy(self, stream, first_ids, max_new_tokens, eos_token_id, repetition_penalty=None, generated_token_ids=None):
-        """fast_greedy_generate (models/modeling_live.py:64-90) on the oracle."""
+    def generate_greedy(self, stream, first_ids, max_new_tokens, eos_token_id, repetition_penalty=None, generated_token_ids=None,
+                        chunk=None, between_chunks=None):
+        """fast_greedy_generate (models/modeling_live.py:64-90) on the oracle; `chunk`: the same response produced in several
+        calls, each continuing from the previous chunk's last id (what the product's chunked generation does)."""
+        if chunk:
+            out, ids = [], first_ids
+            while len(out) < max_new_tokens:
+                part = self.generate_greedy(stream, ids, min(chunk, max_new_tokens - len(out)), eos_token_id, repetition_penalty, generated_token_ids)
+                out += part
+                if out[-1] == eos_token_id:
+                    break
+                ids = torch.tensor([[out[-1]]])
+                if between_chunks is not None and len(out) < max_new_tokens:
+                    between_chunks()
+            return out
         emb = self.embed_tokens(first_ids).view(1, -1, self.hidden_size)
         out = []
         for _ in range(max_new_tokens):

@@ -424,3 +424,41 @@ def test_device_ring_reproduces_the_reference_cache_classes_bit_for_bit():
         st.close()
     assert checked == 3 * 4 * CACHE_LAYERS
     rt.close()
+
+
+@pytest.mark.gpu
+def test_python_cache_classes_update_reproduces_the_reference_fixture():
+    """The drop-in's SinkCache / SlidingWindowCache / TrulyStaticCache objects take the reference's operator call
+    `update(key_states, value_states, layer_idx, cache_kwargs)` (test/sink_cache.py:74-80) and return, bit for bit, what the
+    imported reference classes returned when tests/golden/cache_policies.npz was generated."""
+    import dataclasses
+    from aha_amd.cache import SinkCache, SlidingWindowCache, TrulyStaticCache
+    from aha_amd.config import preset
+    from aha_amd.runtime import Runtime
+    from make_golden import CACHE_D, CACHE_HKV, CACHE_LAYERS, CACHE_SINK, CACHE_STEPS, CACHE_THETA, CACHE_W, bf16_bits, cache_inputs
+    base = preset("tiny")
+    cfg = dataclasses.replace(base, lm=dataclasses.replace(base.lm, num_hidden_layers=CACHE_LAYERS, num_key_value_heads=CACHE_HKV,
+                                                           head_dim=CACHE_D, rope_theta=CACHE_THETA), name="cachegold")
+    rt = Runtime(cfg, make_weights(cfg, dtype=torch.bfloat16), max_step_tokens=64, max_vit_frames=1, max_positions=1024)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "cache_policies.npz"))
+    checked = 0
+    for name, cache in (("sink", SinkCache(CACHE_W, CACHE_SINK)), ("sliding", SlidingWindowCache(CACHE_W)), ("static", TrulyStaticCache(CACHE_W))):
+        with pytest.raises(RuntimeError):
+            cache.update(torch.zeros(1, CACHE_HKV, 1, CACHE_D), torch.zeros(1, CACHE_HKV, 1, CACHE_D), 0)      # unbound: loud
+        cache.bind(rt)
+        assert cache.get_max_length() == CACHE_W and cache.get_max_cache_shape() == CACHE_W
+        for step, (T, layers) in enumerate(cache_inputs()):
+            assert cache.get_seq_length() == int(gold[f"{name}_len_before"][step]), (name, step)
+            for l, (k, v) in enumerate(layers):
+                kw = {"sin": None, "cos": None, "cache_position": None}                # 4.49-style kwargs: accepted, unused
+                Kr, Vr = cache.update(k.cuda()[None] if k.dim() == 3 else k.cuda(), v.cuda()[None] if v.dim() == 3 else v.cuda(), l, kw)
+                assert Kr.dim() == 4 and Kr.shape[0] == 1
+                if f"{name}_k_s{step}_l{l}" in gold:
+                    assert np.array_equal(bf16_bits(Kr.cpu()), gold[f"{name}_k_s{step}_l{l}"]), (name, step, l, "K")
+                    assert np.array_equal(bf16_bits(Vr.cpu()), gold[f"{name}_v_s{step}_l{l}"]), (name, step, l, "V")
+                    checked += 1
+        assert cache.get_seq_length() == int(gold[f"{name}_len_final"]) and cache._seen_tokens == sum(CACHE_STEPS)
+        cache.reset()
+        assert cache.get_seq_length() == 0
+    assert checked == 3 * 4 * CACHE_LAYERS
+    rt.close()

@@ -75,6 +75,40 @@ def test_driver_responses_and_score_sum_rule():
     assert drv.past_key_values.get_seq_length() == ora.past_key_values.get_seq_length()
 
 
+def test_chunked_response_generation_gives_the_same_conversation():
+    """A response written in chunks of 3 tokens (other streams may step in between) == the one-call response."""
+    cfg, tok, drv, ora = _pair("default_sink", stream_end_score_sum_threshold=2.0, repetition_penalty=1.2)
+    calls = []
+    drv.generation_chunk, drv.between_chunks = 3, lambda: calls.append(drv.video_time)
+    frames = make_frames(8, cfg.vision.image_size, seed=4)
+    drv.input_video_stream(frames)
+    ora.input_video_stream(frames)
+    got, want = drv.inference(), ora.inference()
+    assert len(got) == len(want) >= 1 and calls
+    for a, b in zip(got, want):
+        assert a["time"] == pytest.approx(b["time"]) and a["content"] == tok.decode(b["content"])
+    assert drv.past_key_values.get_seq_length() == ora.past_key_values.get_seq_length()
+    assert drv.generated_token_ids == ora.generated_token_ids
+
+
+def test_demo_driver_shares_the_trigger_rule_with_the_benchmark_driver():
+    """input_one_frame (test/live_infer_for_video.py:135-176) and inference (test/inference.py:283-335) fire on the same frames."""
+    from aha_amd.live_infer import LiveInferForDemo
+    cfg = preset("tiny")
+    w = make_weights(cfg, dtype=torch.float32)
+    args = LiveTestArguments(stream_end_score_sum_threshold=2.0, running_list_length=3)
+    bench = LiveInferForBenchmark(args, runtime=OracleBackedRuntime(cfg, w))
+    demo = LiveInferForDemo(args, runtime=OracleBackedRuntime(cfg, w))
+    frames = make_frames(8, cfg.vision.image_size, seed=4)
+    bench.input_video_stream(frames)
+    turns = bench.inference()
+    demo.input_video_stream(frames)
+    rows = [demo.input_one_frame() for _ in range(8)]
+    assert [r["time"] for r in rows if r["response"] is not None] == [pytest.approx(t["time"], abs=0.05) for t in turns]
+    assert len(demo.stream_end_prob_list) == 3 and demo.stream_end_prob_list == bench.stream_end_prob_list
+    assert demo.stream_end_score_sum == pytest.approx(bench.stream_end_score_sum)
+
+
 def test_threshold_validation_and_reset():
     cfg = preset("tiny")
     w = make_weights(cfg, dtype=torch.float32)
