@@ -311,6 +311,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_lm") aha_attention_set_lm_kernel(value);   // 1 (default): frame-sized LM steps use attn_lm_kernel (LDS-DMA, all row tiles per workgroup)
+    else if (k == "attn_head") aha_attention_set_head_kernel(value);   // whole-head-in-LDS dense (ViT) attention: 0 off, 1 auto, 2 always when eligible
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
     else if (k == "tile_epi") aha_gemm_tile_set_epi(value);      // 1 (default): LDS-transposed wide epilogue of the LDS-DMA tile kernels      // 0 off, 1 auto (default), 2 force
@@ -722,6 +723,7 @@ static hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ld
     return aha_gemm_tile(&g, st);
 }
 
+static int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st);
 static int vit_tower(aha_ctx* c, const uint8_t* frames, int n, hipStream_t st) {
     const aha_model_desc& d = c->d;
     const bool clip = d.v_kind == AHA_VISION_CLIP;
@@ -737,8 +739,17 @@ static int vit_tower(aha_ctx* c, const uint8_t* frames, int n, hipStream_t st) {
         HIPCHK(c, aha_clip_assemble(c->v_patch, c->cls_emb, c->pos_emb, c->v_h, n, c->Np, Dv, st));
         HIPCHK(c, aha_layernorm(c->v_h, Dv, c->pre_ln_w, c->pre_ln_b, c->v_x, Dv, rows, Dv, d.v_ln_eps, st));
     }
+    return vit_layers(c, n, 0, d.v_layers, st);
+}
+
+// Encoder layers [l0, l1) of the tower on the hidden state in c->v_x ([n * Tt][Dv]), in place
+// (SiglipEncoderLayer / CLIPEncoderLayer: pre-LN attention block + pre-LN MLP block, each with its residual).
+static int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
+    const aha_model_desc& d = c->d;
+    const bool clip = d.v_kind == AHA_VISION_CLIP;
+    const int Dv = d.v_hidden, T = c->Tt, rows = n * T, vhd = Dv / d.v_heads;
     const int act = clip ? ACT_QUICK_GELU : ACT_GELU_TANH;
-    for (int l = 0; l < d.v_layers; ++l) {
+    for (int l = l0; l < l1; ++l) {
         const VLayerW& w = c->V[l];
         HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
         HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
@@ -1575,6 +1586,78 @@ extern "C" int aha_attention_forward(aha_ctx* c, aha_stream* const* streams, int
     a.T = T; a.G = d.heads / d.kv_heads; a.Hkv = d.kv_heads; a.split_len = sl; a.n_splits = ns < 1 ? 1 : ns;
     a.scale = 1.0f / sqrtf((float)d.head_dim); a.layer = layer;
     HIPCHK(c, aha_attention(&a, c->sd_dev, B, d.head_dim, st));
+    return 0;
+}
+
+// ---- vision operators (the tower's non-GEMM kernels on caller tensors; the tiled GEMM is aha_linear_tile_forward) ----------
+// SiglipAttention / CLIPAttention core (transformers modeling_siglip.py:116-170): softmax(q k^T / sqrt(head_dim)) v per frame
+// and head, non-causal.  qkv: bf16 [n][T][3*heads*head_dim] (q | k | v concatenated per row, as the tower's fused projection
+// writes them); out: bf16 [n][T][heads*head_dim].
+extern "C" int aha_vit_attention_forward(aha_ctx* c, const void* qkv, int n, int T, int heads, int head_dim, void* out, aha_hip_stream st_) {
+    if (!c || !qkv || !out || n <= 0 || T <= 0 || heads <= 0) return AHA_E_INVAL;
+    if (head_dim < 8 || head_dim > 128 || (head_dim & 7)) return fail(c, AHA_E_INVAL, "head_dim must be a multiple of 8, <= 128");
+    const int Dv = heads * head_dim;
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const bf16*)qkv; a.q_bs = (long)T * 3 * Dv; a.ldq = 3 * Dv;
+    a.k = a.q + Dv; a.v = a.q + 2 * Dv; a.kv_bs = (long)T * 3 * Dv; a.ldk = 3 * Dv;
+    a.out = (bf16*)out; a.o_bs = (long)T * Dv; a.ldo = Dv;
+    a.T = T; a.G = 1; a.Hkv = heads; a.Lk = T;
+    a.split_len = round_up(T, 64); a.n_splits = 1;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    HIPCHK(c, aha_attention(&a, nullptr, n, head_dim, (hipStream_t)st_));
+    return 0;
+}
+// Encoder layers [layer_first, layer_first + layer_count) of the vision tower on a caller-supplied hidden state:
+// x bf16 [n * tokens_per_frame][v_hidden] -> out (same shape); tokens_per_frame = patches (+ 1 class token LAST for CLIP).
+// The per-layer parity tests teacher-force each layer from the oracle's input to it.
+extern "C" int aha_vit_layers_forward(aha_ctx* c, const void* x, int n, int layer_first, int layer_count, void* out, aha_hip_stream st_) {
+    if (!c || !x || !out || n <= 0) return AHA_E_INVAL;
+    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
+    if (n > c->d.max_vit_frames) return fail(c, AHA_E_RANGE, "n_frames > max_vit_frames");
+    if (layer_first < 0 || layer_count <= 0 || layer_first + layer_count > c->d.v_layers) return fail(c, AHA_E_RANGE, "vision layer range");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_VIT(c, st);
+    const size_t bytes = (size_t)n * c->Tt * c->d.v_hidden * 2;
+    HIPCHK(c, hipMemcpyAsync(c->v_x, x, bytes, hipMemcpyDeviceToDevice, st));
+    if (int rc = vit_layers(c, n, layer_first, layer_first + layer_count, st)) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->v_x, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+// nn.LayerNorm over the last dimension (fp32 statistics, bf16 in / out): x bf16 [rows][ldx] -> out bf16 [rows][ldo].
+extern "C" int aha_layernorm_forward(aha_ctx* c, const void* x, int ldx, const void* w, const void* b, void* out, int ldo, int rows, int cols,
+                                     float eps, aha_hip_stream st_) {
+    if (!c || !x || !w || !b || !out || rows <= 0 || cols <= 0 || (cols & 7) || cols > 4096) return AHA_E_INVAL;
+    HIPCHK(c, aha_layernorm((const bf16*)x, ldx, (const bf16*)w, (const bf16*)b, (bf16*)out, ldo, rows, cols, eps, (hipStream_t)st_));
+    return 0;
+}
+// image_processor.preprocess + the unfold of the patch-embedding Conv2d (test/inference.py:176; kernel = stride = patch):
+// uint8 [n][3][S][S] -> bf16 [n * Np][Kp], row = patch (row-major over the patch grid), column = c*P*P + y*P + x of the
+// normalised pixel ((x/255 - mean) / std, rounded to bf16 once), columns >= 3*P*P zero.  *out_cols reports Kp.
+extern "C" int aha_vit_patchify_forward(aha_ctx* c, const uint8_t* frames, int n, void* out, int* out_cols, aha_hip_stream st_) {
+    if (!c || !frames || !out || n <= 0) return AHA_E_INVAL;
+    if (out_cols) *out_cols = c->Kp;
+    HIPCHK(c, aha_im2col_norm(frames, n, c->d.image_size, c->d.patch_size, c->Kp, c->px_mean, c->px_std, (bf16*)out, (hipStream_t)st_));
+    return 0;
+}
+// Spatial pooling of a token grid (video_head_live_llava_qwen.py:117-136; models/vision_live.py:21-24): in bf16 [n][frame_rows][C]
+// whose first grid*grid rows are the row-major patch grid -> out bf16 [n][out_grid^2][C].  mode 0: F.interpolate(bilinear,
+// align_corners=False) to out_grid; 1 / 2: avg / max pool with kernel = stride; 3: adaptive_avg_pool2d to out_grid.
+extern "C" int aha_pool_forward(aha_ctx* c, const void* in, int n, int grid, int out_grid, int C_, int stride, int mode, int frame_rows, void* out,
+                                aha_hip_stream st_) {
+    if (!c || !in || !out || n <= 0 || grid <= 0 || out_grid <= 0 || C_ <= 0 || (C_ & 3) || mode < 0 || mode > 3) return AHA_E_INVAL;
+    if (frame_rows < grid * grid) return fail(c, AHA_E_RANGE, "frame_rows < grid^2");
+    HIPCHK(c, aha_pool((const bf16*)in, (bf16*)out, n, grid, out_grid, C_, stride, mode, frame_rows, (hipStream_t)st_));
+    return 0;
+}
+// The rows of the patch grid that bilinear pooling with an even integer stride samples (2*out_grid per side), compacted:
+// in bf16 [n][frame_rows][C] -> out bf16 [n][(2*out_grid)^2][C] (the projector then runs on these rows only; aha_vit_encode).
+extern "C" int aha_pool_gather_rows_forward(aha_ctx* c, const void* in, int n, int grid, int out_grid, int C_, int frame_rows, void* out,
+                                            aha_hip_stream st_) {
+    if (!c || !in || !out || n <= 0 || grid <= 0 || out_grid <= 0 || C_ <= 0 || (C_ & 7)) return AHA_E_INVAL;
+    const int s = grid / out_grid;
+    if (grid % out_grid || s < 4 || (s & 1)) return fail(c, AHA_E_RANGE, "needs an even integer stride >= 4");
+    HIPCHK(c, aha_gather_pool_rows((const bf16*)in, (bf16*)out, n, grid, out_grid, s, C_, frame_rows, (hipStream_t)st_));
     return 0;
 }
 

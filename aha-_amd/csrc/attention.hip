@@ -472,6 +472,177 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dense attention with the WHOLE head LDS-resident (round 3): at 576 keys x 64 channels the K and V of one (frame, head) are
+// 2 x 72 KB - they fit the CU's 160 KB.  One workgroup of NW waves owns one (frame, head): K and V go into LDS ONCE by LDS-DMA
+// (global_load_lds_dwordx4, swizzles on the source address), and after one barrier every wave runs its TPW query tiles over
+// all key blocks with no synchronisation at all - attn_dense_kernel restages every 64-key block through registers for each
+// 64-row group (9 x per head) behind two barriers per block and measured 108 us per 32-frame layer, three times its VALU
+// time.
+// LDS images, 128-byte rows (8 chunks of 16 B), lane-linear DMA destinations:
+//   K: chunk c of key r at slot c ^ (r & 7)             -> conflict-free ds_read_b128 A fragments (as attn_dense_kernel)
+//   V: chunk c of key r at slot c ^ (2 * ((r >> 1) & 3)) -> conflict-free ds_read_b64_tr_b16: a 32-lane half reads 8 rows x 32 B;
+//      rows are 32 banks apart, so rows r and r+2 would collide - the XOR moves each row pair to its own 32-byte column.
+// A row's arithmetic is instruction for instruction that of attn_dense_kernel (same 64-key blocks, same online softmax in the
+// base-2 domain, same MFMA order): bit-identical results, so the choice of kernel (which depends on the geometry only, never
+// on the batch) cannot change an embedding.
+// ---------------------------------------------------------------------------------------------
+template <int NW, int TPW>
+__global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk_pad) {
+    constexpr int D = 64;
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
+    bf16* Ks = reinterpret_cast<bf16*>(dsm_raw);
+    bf16* Vs = Ks + (long)lk_pad * D;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q4 = lane >> 4, r16 = lane & 15;
+    const int b = blockIdx.y, hk = blockIdx.x;
+    const int R = a.G * a.T, RT = ceil_div(R, 16);
+    const int Lk = a.Lk, ldk = a.ldk;
+    const bf16* kb = a.k + b * a.kv_bs + hk * D;
+    const bf16* vb = a.v + b * a.kv_bs + hk * D;
+    const int j1 = Lk;
+
+    // ---- K then V into LDS: piece = 8 key rows (1 KiB); every wave issues the same number of pieces per operand (surplus
+    // ones repeat the last piece: same bytes to the same place), so the counted wait below is the same for all waves
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int np = lk_pad >> 3, pw = ceil_div(np, NW);
+    {
+        const int lr = lane >> 3, sl = lane & 7;
+        for (int i = 0; i < pw; ++i) {
+            const int pc = min(wave + i * NW, np - 1), row = pc * 8 + lr;
+            const bf16* src = kb + (long)min(row, j1 - 1) * ldk + ((sl ^ (row & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ks + pc * 512), 16, 0, 0);
+        }
+        for (int i = 0; i < pw; ++i) {
+            const int pc = min(wave + i * NW, np - 1), row = pc * 8 + lr;
+            const bf16* src = vb + (long)min(row, j1 - 1) * ldk + ((sl ^ (2 * ((row >> 1) & 3))) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + pc * 512), 16, 0, 0);
+        }
+    }
+
+    const int rt0 = wave * TPW;
+    const bool wave_on = rt0 < RT;
+    bool row_ok[TPW];
+    int trow[TPW], thead[TPW];
+    bf16x8 qf[TPW][C::KSQ];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        int r = (rt0 + tt) * 16 + r16;
+        row_ok[tt] = (rt0 + tt) < RT && r < R;
+        if (r > R - 1) r = R - 1;
+        trow[tt] = r % a.T;
+        thead[tt] = hk * a.G + r / a.T;
+        const bf16* qp = a.q + b * a.q_bs + (long)trow[tt] * a.ldq + thead[tt] * D;
+#pragma unroll
+        for (int ks = 0; ks < C::KSQ; ++ks) qf[tt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 32 + q4 * 8);
+    }
+    f32x4 o[TPW][C::DT];
+    float m_run[TPW], l_run[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        m_run[tt] = -INFINITY;
+        l_run[tt] = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::DT; ++i) o[tt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int vrow = 4 * q4 + (r16 >> 2), vcol = 4 * (r16 & 3);
+    const float c2 = a.scale * 1.4426950408889634f;                 // scale * log2(e)
+
+    // Everything this wave issued has landed (the Q fragments are ordinary loads, the youngest entries of its queue: hipcc
+    // waits vmcnt(0) at their first use anyway while LDS-DMA is in flight), then every wave's pieces have
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int jb = 0; jb < j1; jb += 64) {
+        bf16x8 pb[TPW][2];
+        const bool tail = jb + 64 > j1;                              // uniform
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int row = jb + kt * 16 + r16;
+#pragma unroll
+                for (int ks = 0; ks < C::KSQ; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (row & 7)) << 3)]);
+                    s[kt] = mfma16(kf, qf[tt][ks], s[kt]);
+                }
+            }
+            if (tail) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (jb + kt * 16 + 4 * q4 + e >= j1) s[kt][e] = -INFINITY;
+            }
+            float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) bmax = fmaxf(bmax, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const float m_new = fmaxf(m_run[tt], bmax * c2);         // -inf * c2 = -inf
+            float alpha = 1.f, psum = 0.f;
+            if (m_new == -INFINITY) {
+                pb[tt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                pb[tt][1] = pb[tt][0];
+            } else {
+                alpha = __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf -> 0
+                const float nm = -m_new;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
+                        psum += p;
+                        pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                    }
+            }
+            m_run[tt] = m_new;
+            l_run[tt] = l_run[tt] * alpha + psum;
+#pragma unroll
+            for (int i = 0; i < C::DT; ++i) o[tt][i] *= alpha;
+            if (TPW > 1) __builtin_amdgcn_sched_barrier(0);          // keep the tiles sequential (hipcc would re-merge them)
+        }
+        // ---- O^T += V^T P^T: one transposed V fragment feeds TPW MFMAs
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                const int r0 = jb + (2 * kp) * 16 + vrow, r1 = r0 + 16;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[r0 * D + (((2 * dt + (vcol >> 3)) ^ (2 * ((r0 >> 1) & 3))) << 3) + (vcol & 7)]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4)(&Vs[r1 * D + (((2 * dt + (vcol >> 3)) ^ (2 * ((r1 >> 1) & 3))) << 3) + (vcol & 7)]));
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) o[tt][dt] = mfma16(vf, pb[tt][kp], o[tt][dt]);
+            }
+        }
+    }
+    if (!wave_on) return;
+#pragma unroll
+    for (int tt = 0; tt < TPW; ++tt) {
+        float l = l_run[tt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (!row_ok[tt]) continue;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * D + 4 * q4;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt) {
+            bf16x4 ov = {f2bf(o[tt][dt][0] * inv), f2bf(o[tt][dt][1] * inv), f2bf(o[tt][dt][2] * inv), f2bf(o[tt][dt][3] * inv)};
+            *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LM attention for frame-sized steps (more than 64 query rows per KV head: T = 36 tokens x 7 query heads = 252 rows).
 // attn_fwd_kernel gives every 64-row group its own workgroup, so each (stream, KV head, key split) is staged from HBM/L2 into
 // LDS four times, through registers, with one block of keys in flight per workgroup: at L_kv = 2,048 it measured 11.5 us
@@ -769,6 +940,8 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
 
 static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of the dense kernel (0 = auto, 1..3 forced)
 extern "C" void aha_attention_set_dense_tpw(int v) { g_dense_tpw = v; }
+static int g_attn_head = 1;      // tuning "attn_head": whole-head-in-LDS dense attention (0 off, 1 auto, 2 always when eligible)
+extern "C" void aha_attention_set_head_kernel(int v) { g_attn_head = v; }
 static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-sized steps (> 64 rows per KV head, head_dim 128): 0 never, 1 auto, 2 always
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
@@ -808,6 +981,23 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
         // packed fp32 ops and skipping idle rescales did not move it either (profiles/r02_vit_batch.txt): the per-block chain
         // barrier -> fragment reads -> MFMA -> softmax -> MFMA runs with little overlap at ~108 us.  Default: one tile per wave, the
         // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
+        if constexpr (D == 64) {
+            // whole head LDS-resident (attn_head64_kernel): 64-wide heads whose K + V fit the CU's LDS and whose query rows fit
+            // 12 waves x 3 tiles; needs enough (frame, head) pairs to give every CU a workgroup (single-frame latency stays
+            // on the restaging kernel: 16 workgroups would leave the chip empty).  Tuning "attn_head": 0 off, 1 auto, 2 always.
+            const int lk_pad = round_up(a.Lk, 64), lds = 2 * lk_pad * 64 * 2;
+            if (g_attn_head && a.hd == 64 && lds <= 160 * 1024 - 1024 && RT <= 36 && a.Lk >= 64 &&
+                (g_attn_head == 2 || a.Hkv * B >= 128)) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    hipError_t e = hipFuncSetAttribute((const void*)attn_head64_kernel<12, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) return e;
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((attn_head64_kernel<12, 3>), dim3(a.Hkv, B), dim3(768), lds, st, a, lk_pad);
+                return hipGetLastError();
+            }
+        }
         int tpw = g_dense_tpw == 0 ? 1 : g_dense_tpw;
         if (D > 64) tpw = 1;
         if (tpw == 3) {

@@ -78,6 +78,12 @@ SYMBOLS = [
     ("aha_heads_forward", _I, [_P, _P, _I, _I, _P, _P, _P]),
     ("aha_cache_update", _I, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
     ("aha_attention_forward", _I, [_P, C.POINTER(_P), _I, _P, _I, _I, C.POINTER(_I), _I, _P, _P]),
+    ("aha_vit_attention_forward", _I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    ("aha_vit_layers_forward", _I, [_P, _P, _I, _I, _I, _P, _P]),
+    ("aha_layernorm_forward", _I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
+    ("aha_vit_patchify_forward", _I, [_P, _P, _I, _P, C.POINTER(_I), _P]),
+    ("aha_pool_forward", _I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    ("aha_pool_gather_rows_forward", _I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     ("aha_lm_debug_tap", _I, [_P, _I, _P, _P]),
     ("aha_comm_unique_id", _I, [_P, C.c_size_t]),
     ("aha_comm_init_rank", _I, [_P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),

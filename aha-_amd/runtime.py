@@ -412,6 +412,57 @@ class Runtime:
         self._chk(self.lib.aha_attention_forward(self.ctx, arr, B, q.data_ptr(), T, int(layer), co, int(split_len), out.data_ptr(), _cur_stream()))
         return out
 
+    # -- vision operators (include/aha_amd.h "vision operators") -----------------------------------------------------------
+    def vit_attention(self, qkv: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
+        """qkv bf16 [n,T,3*heads*head_dim] (q | k | v per row) -> softmax(q k^T / sqrt(d)) v, bf16 [n,T,heads*head_dim]."""
+        qkv = qkv.contiguous()
+        n, T, _ = qkv.shape
+        out = torch.empty((n, T, heads * head_dim), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_vit_attention_forward(self.ctx, qkv.data_ptr(), n, T, int(heads), int(head_dim), out.data_ptr(), _cur_stream()))
+        return out
+
+    def vit_layers(self, x: torch.Tensor, n_frames: int, layer_first: int, layer_count: int = 1) -> torch.Tensor:
+        """Encoder layers of the vision tower on a caller-supplied hidden state bf16 [n*tokens, Dv]."""
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        self._chk(self.lib.aha_vit_layers_forward(self.ctx, x.data_ptr(), int(n_frames), int(layer_first), int(layer_count), out.data_ptr(), _cur_stream()))
+        return out
+
+    def layernorm(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+        x = x.contiguous()
+        rows, cols = x.shape
+        out = torch.empty_like(x)
+        self._chk(self.lib.aha_layernorm_forward(self.ctx, x.data_ptr(), cols, w.data_ptr(), b.data_ptr(), out.data_ptr(), cols, rows, cols,
+                                                 float(eps), _cur_stream()))
+        return out
+
+    def vit_patchify(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [n,3,S,S] -> bf16 [n*Np, Kp] normalised patch vectors (preprocess + conv unfold; zero padding beyond 3*P*P)."""
+        frames_u8 = frames_u8.contiguous()
+        n = frames_u8.shape[0]
+        v = self.cfg.vision
+        kp = -(-(3 * v.patch_size * v.patch_size) // 64) * 64
+        out = torch.empty((n * v.num_patches, kp), dtype=torch.bfloat16, device=self.device)
+        cols = C.c_int(0)
+        self._chk(self.lib.aha_vit_patchify_forward(self.ctx, frames_u8.data_ptr(), n, out.data_ptr(), C.byref(cols), _cur_stream()))
+        assert cols.value == kp
+        return out
+
+    def pool(self, x: torch.Tensor, grid: int, out_grid: int, stride: int, mode: int) -> torch.Tensor:
+        """x bf16 [n, rows >= grid^2, C] -> bf16 [n, out_grid^2, C]; mode 0 bilinear, 1 average, 2 max, 3 adaptive average."""
+        x = x.contiguous()
+        n, rows, ch = x.shape
+        out = torch.empty((n, out_grid * out_grid, ch), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_pool_forward(self.ctx, x.data_ptr(), n, int(grid), int(out_grid), ch, int(stride), int(mode), rows, out.data_ptr(), _cur_stream()))
+        return out
+
+    def pool_gather_rows(self, x: torch.Tensor, grid: int, out_grid: int) -> torch.Tensor:
+        x = x.contiguous()
+        n, rows, ch = x.shape
+        out = torch.empty((n, 4 * out_grid * out_grid, ch), dtype=torch.bfloat16, device=self.device)
+        self._chk(self.lib.aha_pool_gather_rows_forward(self.ctx, x.data_ptr(), n, int(grid), int(out_grid), ch, rows, out.data_ptr(), _cur_stream()))
+        return out
+
     def debug_tap(self, which: str, B: int, T: int) -> torch.Tensor:
         d = self.desc
         idx, cols = {"h": (0, d.hidden), "xn": (1, d.hidden), "q_rot": (2, d.heads * d.head_dim), "attn_out": (3, d.heads * d.head_dim),

@@ -293,6 +293,31 @@ int aha_lm_last_step_work(aha_ctx* ctx, double* weight_bytes, double* kv_bytes, 
 int aha_lm_last_gemm_time(aha_ctx* ctx, int kind, float* ms, int* launches, double* gemm_weight_bytes);
 const char* aha_version(void);
 
+/* ---- vision operators: the tower's non-GEMM kernels on caller tensors (its GEMMs are aha_linear_tile_forward).  The parity
+ * tests bound each of them against an exact reference; an integrator can swap them in for the reference's modules. ------------ */
+/* SiglipAttention / CLIPAttention core (the attention the vision tower of video_head_live_llava_qwen.py:113-115 runs):
+ * softmax(q k^T / sqrt(head_dim)) v per frame and head, non-causal.  qkv: bf16 [n][T][3*heads*head_dim] (q | k | v per row);
+ * out: bf16 [n][T][heads*head_dim]. */
+int aha_vit_attention_forward(aha_ctx* ctx, const void* qkv, int n_frames, int T, int heads, int head_dim, void* out, aha_hip_stream st);
+/* SiglipEncoderLayer / CLIPEncoderLayer layer_first .. layer_first + layer_count - 1 of the tower (the arithmetic the tower of
+ * video_head_live_llava_qwen.py:113-115 runs per layer) on a caller-supplied hidden state: x bf16 [n * tokens][v_hidden] -> out. */
+int aha_vit_layers_forward(aha_ctx* ctx, const void* x, int n_frames, int layer_first, int layer_count, void* out, aha_hip_stream st);
+/* nn.LayerNorm (fp32 statistics) of the tower's layer_norm1 / layer_norm2 / post_layernorm: bf16 [rows][ldx] -> bf16 [rows][ldo]. */
+int aha_layernorm_forward(aha_ctx* ctx, const void* x, int ldx, const void* weight, const void* bias, void* out, int ldo, int rows, int cols,
+                          float eps, aha_hip_stream st);
+/* image_processor.preprocess (test/inference.py:176) fused with the unfold of the patch-embedding conv: uint8 [n][3][S][S] ->
+ * bf16 [n*Np][Kp] normalised patch vectors (column c*P*P + y*P + x; columns >= 3*P*P are zero padding); *out_cols = Kp. */
+int aha_vit_patchify_forward(aha_ctx* ctx, const uint8_t* frames_u8, int n_frames, void* out, int* out_cols, aha_hip_stream st);
+/* post_projector_pooling (video_head_live_llava_qwen.py:117-136) / adaptive_avg_pool2d (models/vision_live.py:21-24) of a token
+ * grid: in bf16 [n][frame_rows][C], first grid^2 rows = the patch grid -> out bf16 [n][out_grid^2][C].  mode 0 bilinear
+ * (align_corners=False), 1 average, 2 max (kernel = stride), 3 adaptive average. */
+int aha_pool_forward(aha_ctx* ctx, const void* in, int n_frames, int grid, int out_grid, int channels, int stride, int mode, int frame_rows,
+                     void* out, aha_hip_stream st);
+/* the (2*out_grid)^2 patch rows per frame that bilinear pooling with an even integer stride reads, compacted (aha_vit_encode
+ * runs the projector on these only): in bf16 [n][frame_rows][C] -> out bf16 [n][(2*out_grid)^2][C]. */
+int aha_pool_gather_rows_forward(aha_ctx* ctx, const void* in, int n_frames, int grid, int out_grid, int channels, int frame_rows, void* out,
+                                 aha_hip_stream st);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,29 +54,48 @@ class OracleVision:
                      w["vision.embeddings.patch_embedding.bias"], stride=v.patch_size)
         x = x.flatten(2).transpose(1, 2)
         x = x + w["vision.embeddings.position_embedding.weight"][None]
+        for i in range(v.num_hidden_layers):
+            x = self.encoder_layer(x, i)
+        return x
+
+    @torch.no_grad()
+    def layer_inputs(self, pixel_values: torch.Tensor):
+        """The hidden state entering every encoder layer, plus the tower output (teacher-forcing taps of the per-layer parity tests)."""
+        v, w = self.v, self.w
+        x = F.conv2d(pixel_values, w["vision.embeddings.patch_embedding.weight"],
+                     w["vision.embeddings.patch_embedding.bias"], stride=v.patch_size)
+        x = x.flatten(2).transpose(1, 2) + w["vision.embeddings.position_embedding.weight"][None]
+        taps = []
+        for i in range(v.num_hidden_layers):
+            taps.append(x)
+            x = self.encoder_layer(x, i)
+        return taps, x
+
+    @torch.no_grad()
+    def encoder_layer(self, x: torch.Tensor, i: int) -> torch.Tensor:
+        """SiglipEncoderLayer i (modeling_siglip.py:327-358): [N,Np,Dv] -> [N,Np,Dv]."""
+        v, w = self.v, self.w
         N, Np, Dv = x.shape
         nh, hd = v.num_attention_heads, v.head_dim
-        for i in range(v.num_hidden_layers):
-            p = f"vision.encoder.layers.{i}."
-            r = x
-            h = F.layer_norm(x, (Dv,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], v.layer_norm_eps)
-            q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
-            k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"])
-            vv = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
-            q = q.view(N, Np, nh, hd).transpose(1, 2)
-            k = k.view(N, Np, nh, hd).transpose(1, 2)
-            vv = vv.view(N, Np, nh, hd).transpose(1, 2)
-            o = F.scaled_dot_product_attention(q, k, vv, scale=hd ** -0.5)
-            o = o.transpose(1, 2).reshape(N, Np, Dv)
-            o = F.linear(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
-            x = r + o
-            r = x
-            h = F.layer_norm(x, (Dv,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], v.layer_norm_eps)
-            h = F.linear(h, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
-            h = F.gelu(h, approximate="tanh")
-            h = F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
-            x = r + h
-        return x
+        p = f"vision.encoder.layers.{i}."
+        r = x
+        h = F.layer_norm(x, (Dv,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], v.layer_norm_eps)
+        q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
+        k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"])
+        vv = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
+        q = q.view(N, Np, nh, hd).transpose(1, 2)
+        k = k.view(N, Np, nh, hd).transpose(1, 2)
+        vv = vv.view(N, Np, nh, hd).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, vv, scale=hd ** -0.5)
+        o = o.transpose(1, 2).reshape(N, Np, Dv)
+        o = F.linear(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+        x = r + o
+        r = x
+        h = F.layer_norm(x, (Dv,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], v.layer_norm_eps)
+        h = F.linear(h, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
+        h = F.gelu(h, approximate="tanh")
+        h = F.linear(h, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+        return r + h
 
     @torch.no_grad()
     def connector(self, feats: torch.Tensor) -> torch.Tensor:
