@@ -97,6 +97,10 @@ hipError_t aha_pack_w(const bf16* W, int N, int K, int ldw, bf16x8* Wp, int KS, 
 hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);
 void aha_gemm_tile_set_epi(int on);
+void aha_gemm_tile_set_p288(int on);
+hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st);
+int aha_gemm_tile_p288_ok(const GemmTileArgs* g);
+float aha_gemm_tile_p288_efficiency(const GemmTileArgs* g, int n_cus);
 void aha_gemm_ws_set_kc_small(int v);
 void aha_attention_set_dense_tpw(int v);
 void aha_attention_set_lm_kernel(int v);

@@ -471,6 +471,27 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
     }
 }
 
+// Butterfly steps over lanes l ^ 16 and l ^ 32 on the vector ALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of
+// ds_bpermute round trips through the LDS: swap(x, x) leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (16-lane rows) resp. [lo lo] / [hi hi]
+// (32-lane halves) in the two results, so one max / add of the pair is the xor-16 / xor-32 reduction step in every lane.  max is
+// exact and the adds are commutative: same bits as the __shfl_xor form.
+static __device__ __forceinline__ float xor16_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor32_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor16_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ float xor32_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dense attention with the WHOLE head LDS-resident (round 3): at 576 keys x 64 channels the K and V of one (frame, head) are
 // 2 x 72 KB - they fit the CU's 160 KB.  One workgroup of NW waves owns one (frame, head): K and V go into LDS ONCE by LDS-DMA
@@ -584,8 +605,8 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
             float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
             for (int kt = 1; kt < 4; ++kt) bmax = fmaxf(bmax, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            bmax = xor16_max(bmax);                                  // lanes l, l^16, l^32, l^48 hold one query row's keys
+            bmax = xor32_max(bmax);
             const float m_new = fmaxf(m_run[tt], bmax * c2);         // -inf * c2 = -inf
             float alpha = 1.f, psum = 0.f;
             if (m_new == -INFINITY) {
@@ -629,8 +650,8 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
 #pragma unroll
     for (int tt = 0; tt < TPW; ++tt) {
         float l = l_run[tt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = xor16_sum(l);
+        l = xor32_sum(l);
         if (!row_ok[tt]) continue;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * D + 4 * q4;

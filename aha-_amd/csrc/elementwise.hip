@@ -470,6 +470,9 @@ __global__ __launch_bounds__(256) void heads_kernel(const bf16* __restrict__ xn,
 struct PixelNorm { float mean[3], std[3]; };
 __global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, int S, int P, int grid, int Kp, PixelNorm pn,
                                    bf16* __restrict__ out) {
+    // torch evaluates frames * (1/255), the subtraction and the division as three separately rounded fp32 ops: no FMA contraction
+    // (a fused u * c - mean differs in the last fp32 bit and flips a bf16 rounding now and then: tests/test_gpu_vision_kernels.py)
+#pragma clang fp contract(off)
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int kch = Kp >> 3;
     const long total = (long)N * grid * grid * kch;

@@ -10,23 +10,9 @@
 // receives (ids equal mod 8) walk consecutive n-tiles of the same m-panel (A panel stays in
 // that XCD's L2).
 #include "aha_kernels.h"
-
+#include "tile_act.h"
 
 #define TBK 64
-
-static __device__ __forceinline__ float gelu_tanh_f(float x) {
-    // torch gelu(approximate='tanh'): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-    const float k = 0.7978845608028654f;
-    const float inner = k * (x + 0.044715f * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
-}
-static __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
-// transformers QuickGELUActivation on bf16 tensors: input * sigmoid(1.702 * input), each op rounded to bf16
-static __device__ __forceinline__ float quick_gelu_bf16(float x) {
-    const float t = rbf(1.702f * x);
-    const float s = rbf(1.0f / (1.0f + __expf(-t)));
-    return x * s;                                     // the caller rounds the product
-}
 
 // WT = 16x16 MFMA tiles per wave per dimension: WT = 4 -> 128x128 block tile (throughput shapes),
 // WT = 2 -> 64x64 block tile (M <= ~1k rows: single-frame latency; 4x the workgroups).
@@ -852,6 +838,8 @@ static hipError_t launch_256(const GemmTileArgs* g, hipStream_t st) {
 // tuning "tile_dma": 0 disables the LDS-DMA family, 1 auto, >= 2 forces variant id (tests, sweeps) whenever K allows
 static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
+static int g_tile_p288 = 1;      // tuning "tile_p288": persistent 288x256 kernel where its decomposition fits (0: round-2 variants only)
+extern "C" void aha_gemm_tile_set_p288(int on) { g_tile_p288 = on; }
 static int g_tile_epi = 1;       // tuning "tile_epi": 1 = LDS-transposed wide epilogue (default), 0 = direct 8-byte stores
 extern "C" void aha_gemm_tile_set_epi(int on) { g_tile_epi = on; }
 
@@ -884,6 +872,7 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
         case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
+        case 12: return aha_gemm_tile_p288_ok(g) && g->wide_epi ? aha_gemm_tile_p288(g, st) : launch_dma32<4, 4, 4, 2, 3>(g, st);   // persistent 288x256 (gemm_tile_p.hip)
         default: return hipErrorInvalidValue;
     }
 }
@@ -915,6 +904,12 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
         if (v == 10) {                                   // experiment: auto, but 256x256 (fewest operand bytes) on wide large grids
             const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
             v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
+        }
+        if (v == 1 && g_tile_p288 && g->wide_epi && aha_gemm_tile_p288_ok(g) && aha_gemm_tile_p288_efficiency(g, 256) >= 0.74f) {
+            // throughput shapes whose 288 x 256 decomposition keeps the chip busy (tile padding x round quantisation >= 0.74:
+            // every tower and projector GEMM from 8 frames of 576 patches up): the persistent kernel (gemm_tile_p.hip).
+            // Tuning "tile_p288" = 0 keeps the round-2 selection below.
+            v = 12;
         }
         if (v == 1) {
             // 576-patch towers: M is a multiple of 288.  The 288x128 tile is ~10 % slower per flop than 256x128 (11 fragment

@@ -1,0 +1,274 @@
+// Persistent 288 x 256 tiled MFMA GEMM for the vision tower's throughput shapes (round 3):
+//     C[M,N] = epilogue( A[M,K] * W[N,K]^T + bias )          (same contract as gemm_tile.hip: GemmTileArgs)
+//
+// Why another tile.  profiles/r02_gemm_tile_epilogue.txt: the 256x128 LDS-DMA kernels run the tower's K = 1024 GEMMs at
+// 0.60-0.88 PF with a fixed cost of ~44 us inside a 153 us launch, and their LDS is ~88 % busy: a 64x64 wave tile reads
+// (64+64) operand rows per 64x64 outputs.  Here:
+//   * wave tile 144 x 64 (9 x 4 accumulator tiles, 36 MFMAs per 13 fragment reads per 32-deep k-step): 0.65x the LDS read
+//     bytes per flop of the 64x64 wave tile; block tile 288 x 256, 8 waves as 2 (M) x 4 (N), one workgroup per CU.
+//   * 288 divides the 576 patches of a ViT-L/14@336 frame: M = 576 n has no ragged m-tile, and at 32 frames the tower's
+//     GEMMs are 768 (QKV), 256 (out-proj, fc2) and 1024 (fc1) tiles = exactly 3 / 1 / 4 rounds of the 256 CUs.
+//   * PERSISTENT: a workgroup walks its tiles (t = blockIdx + j * gridDim) as ONE continuous stream of k-steps.  The LDS-DMA
+//     prefetch (4 stages of 34 KB, three k-steps ahead, counted vmcnt, one raw s_barrier per k-step) runs across tile
+//     boundaries, so the first stages of the next tile are already in flight while the finished tile's epilogue runs - no
+//     pipeline fill per tile, no launch tail between the tiles of a GEMM.
+//   * epilogue through a private 2.3 KB LDS slab per wave, outside the stage ring: one 16-row tile at a time, bf16 tile
+//     written row-major, read back as whole 128-byte rows (one cache line per row per wave: the wave's 64 columns) and stored
+//     with the residual / row-add operand added on the way.  Same rounding points as every other tile kernel.
+//   * a stage = 288 A rows + 256 W rows of 64 B = 34 pieces of 1 KiB.  Every wave issues the same five DMA instructions per
+//     k-step - two W pieces, two A pieces and a QUARTER A piece (global_load_lds_dword: 64 lanes x 4 B = four rows) - so
+//     the 34 pieces split evenly over 8 waves with no duplicate bytes and one vmcnt constant for all waves.
+//   * XCD-aware order: the 32 workgroups an XCD runs in a round (blockIdx equal mod 8) take 8 m-panels x 4 n-panels.
+// One output element accumulates its k-steps in the same sequential order as every other variant: bit-identical results
+// (tests/test_gpu_parity.py::test_tiled_gemm_variants_are_bit_identical).
+#include "aha_kernels.h"
+#include "tile_act.h"
+
+namespace {
+constexpr int PBM = 288, PBN = 256, PBK = 32, PSTAGES = 4;
+constexpr int PROWS = PBM + PBN;                   // 544 rows of 64 B per stage
+constexpr int PSTAGE = PROWS * PBK;                // elements per stage (34,816 B)
+constexpr int PWI = 9, PWJ = 4;                    // 16x16 accumulator tiles per wave: 144 rows x 64 columns
+constexpr int PSTG_ST = 64 + 8;                    // epilogue slab row stride (elements): 144 B, keeps ds_read_b128 rows 16-B aligned
+constexpr int PSTG = 16 * PSTG_ST;                 // elements per wave slab
+constexpr int PLDS_BYTES = PSTAGES * PSTAGE * 2 + 8 * PSTG * 2;   // 139,264 + 18,432 = 157,696
+static_assert(PLDS_BYTES <= 160 * 1024, "stage ring + epilogue slabs exceed the CU's LDS");
+constexpr int PPIECES = 5;                         // DMA instructions per wave per k-step
+}
+
+// Tile s of the locality-ordered sequence -> (bm, bn): GROUP_M = 8 m-panels x all n-tiles, column-major inside a group.
+static __device__ __forceinline__ void p288_tile_coords(int s, int tiles_m, int tiles_n, int* bm, int* bn) {
+    const int per_group = 8 * tiles_n, grp = s / per_group, first_m = grp * 8;
+    const int gmn = min(tiles_m - first_m, 8), inner = s - grp * per_group;
+    *bm = first_m + inner % gmn;
+    *bn = inner / gmn;
+}
+
+// Epilogue of one finished 144 x 64 wave tile, one 16-row tile at a time through the wave's private LDS slab; zeroes the
+// accumulators for the next tile.  ACT < 0: activation / operands decided at run time (rare combinations).
+template <int ACT, bool RES, bool ROWADD>
+static __device__ __forceinline__ void p288_epilogue(const GemmTileArgs& g, f32x4 (&acc)[PWI][PWJ], bf16* stg, const int mw, const int nw,
+                                                     const int lane) {
+    const int q = lane >> 4, r16 = lane & 15;
+    const int act = ACT < 0 ? g.act : ACT;
+    const bool res = ACT < 0 ? g.residual != nullptr : RES, radd = ACT < 0 ? g.rowadd != nullptr : ROWADD;
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[PWJ];
+#pragma unroll
+    for (int j = 0; j < PWJ; ++j) {
+        const int n = min(nw + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < PWI; ++i) {
+#pragma unroll
+        for (int j = 0; j < PWJ; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(tile_act(acc[i][j][e] + bf2f(bv[j][e]), act));
+            *reinterpret_cast<bf16x4*>(&stg[r16 * PSTG_ST + j * 16 + q * 4]) = o;
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // the slab is private to the wave: its own LDS writes only need to have landed (the compiler's lgkmcnt wait)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 64 + lane, row = idx >> 3, ch = idx & 7;
+            const int m = mw + i * 16 + row, n = nw + ch * 8;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(&stg[row * PSTG_ST + ch * 8]);
+            const int mc = min(m, g.M - 1), nc = min(n, g.N - 8);
+            if (res) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(g.residual + (long)mc * g.ldr + nc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(rv[e]) + bf2f(v[e])));
+            }
+            if (radd) {
+                const bf16x8 pv = *reinterpret_cast<const bf16x8*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + nc);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(v[e]) + bf2f(pv[e])));
+            }
+            if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_tile_p288_kernel(GemmTileArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
+    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 2, wn = wave & 3;
+    bf16* stg = lds + PSTAGES * PSTAGE + wave * PSTG;
+
+    const int T = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
+    const int nk = g.K / PBK;
+    const int my_tiles = bid < T ? (T - bid + G - 1) / G : 0;
+    if (my_tiles == 0) return;
+    const int total = my_tiles * nk;
+    const int full_rounds = T / G;
+    // j-th tile of this workgroup -> position in the locality-ordered sequence.  In a full round the workgroups of one XCD
+    // (blockIdx equal mod 8 under round-robin placement: speed only) take G/8 consecutive positions; the ragged last round
+    // keeps the natural order so that the map stays a bijection onto [0, T).
+    auto seq_of = [&](int j) {
+        if ((G & 7) == 0 && j < full_rounds) return (j * 8 + (bid & 7)) * (G >> 3) + (bid >> 3);
+        return j * G + bid;
+    };
+
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    // ---- DMA side: per-piece source offsets (elements from g.A / g.W, without k) of the tile the prefetch stream is in
+    // pieces 0,1: W rows 16 (wave + 8 i) ...; pieces 2,3: A rows 16 (wave + 8 i) ...; piece 4: A rows 256 + 4 wave .. + 3, 4 B per lane
+    const int prow = lane >> 2, pslot = lane & 3;                    // 16-B pieces: 16 rows x 4 slots
+    const int qrow = lane >> 4, qslot = (lane >> 2) & 3, qbyte = (lane & 3) * 4;   // 4-B quarter piece: 4 rows x 4 slots x 4 dwords
+    unsigned poff[PPIECES];
+    int d_j = 0, d_k = 0;                                            // prefetch stream position: tile index, k-step
+    auto set_tile_offsets = [&](int j) {
+        int bm, bn;
+        p288_tile_coords(seq_of(min(j, my_tiles - 1)), tiles_m, tiles_n, &bm, &bn);
+        const int m0 = bm * PBM, n0 = bn * PBN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int wrow = (wave + 8 * i) * 16 + prow;             // swizzle key: (row >> 2) & 3 with the row index inside its operand
+            poff[i] = (unsigned)min(n0 + wrow, g.N - 1) * (unsigned)g.ldw + ((pslot ^ ((wrow >> 2) & 3)) << 3);
+            const int arow = (wave + 8 * i) * 16 + prow;
+            poff[2 + i] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((pslot ^ ((arow >> 2) & 3)) << 3);
+        }
+        const int arow = 256 + 4 * wave + qrow;
+        poff[4] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((qslot ^ ((arow >> 2) & 3)) << 3);
+    };
+    const char* Ab = reinterpret_cast<const char*>(g.A);
+    const char* Wb = reinterpret_cast<const char*>(g.W);
+    // issue piece i of the prefetch stream's current k-step into stage `st`
+    auto dma_piece = [&](int i, int st, int k0) {
+        bf16* sb = lds + st * PSTAGE;
+        if (i < 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wb + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + (PBM + (wave + 8 * i) * 16) * PBK), 16, 0, 0);
+        else if (i < 4)
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + ((wave + 8 * (i - 2)) * 16) * PBK), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[4] + k0) * 2 + qbyte), (lptr_t)(sb + (256 + 4 * wave) * PBK), 4, 0, 0);
+    };
+    // advance the prefetch stream by one k-step (past the last real step it keeps re-reading the last one into dead stages:
+    // the per-wave vmcnt arithmetic stays the same to the end)
+    auto dma_advance = [&]() {
+        if (++d_k == nk) {
+            d_k = 0;
+            ++d_j;
+            set_tile_offsets(d_j);
+        }
+    };
+
+    f32x4 acc[PWI][PWJ];
+#pragma unroll
+    for (int i = 0; i < PWI; ++i)
+#pragma unroll
+        for (int j = 0; j < PWJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: k-steps 0, 1, 2 of the stream into stages 0, 1, 2
+    set_tile_offsets(0);
+#pragma unroll
+    for (int s = 0; s < PSTAGES - 1; ++s) {
+        const int k0 = d_k * PBK;
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) dma_piece(i, s, k0);
+        dma_advance();
+    }
+
+    int c_j = 0, c_k = 0;                                            // compute stream position
+    int st_cur = 0, st_new = PSTAGES - 1;
+    for (int step = 0; step < total; ++step) {
+        // this wave's pieces of the current k-step have landed (the two younger k-steps stay in flight); after the barrier
+        // everyone's have, and everyone is done reading the stage that is refilled below
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PSTAGES - 2) * PPIECES) : "memory");
+        __builtin_amdgcn_s_barrier();
+
+        const bf16* sa = lds + st_cur * PSTAGE;
+        const bf16* sb = sa + PBM * PBK;
+        const int k0n = d_k * PBK;
+        bf16x8 af[PWI], wf[PWJ];
+#pragma unroll
+        for (int j = 0; j < PWJ; ++j) {
+            const int wrow = wn * (16 * PWJ) + j * 16 + r16;
+            wf[j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * PBK + ((q ^ ((wrow >> 2) & 3)) << 3)]);
+        }
+#pragma unroll
+        for (int i = 0; i < PWI; ++i) {
+            const int row = wm * (16 * PWI) + i * 16 + r16;
+            af[i] = *reinterpret_cast<const bf16x8*>(&sa[row * PBK + ((q ^ ((row >> 2) & 3)) << 3)]);
+        }
+        // 36 MFMAs with the five DMA instructions of k-step (step + 3) spread between them (an LDS-DMA issued while the
+        // matrix pipe is busy costs ~60 cycles; bunched behind the barrier 100-185 each with nothing to overlap)
+        constexpr int NM = PWI * PWJ, PER = NM / (PPIECES + 1);
+#pragma unroll
+        for (int i = 0; i < PWI; ++i)
+#pragma unroll
+            for (int j = 0; j < PWJ; ++j) {
+                acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                const int n = i * PWJ + j + 1;
+                if (n % PER == 0 && n / PER <= PPIECES) dma_piece(n / PER - 1, st_new, k0n);
+            }
+        __builtin_amdgcn_sched_group_barrier(0x100, PWI + PWJ, 0);             // DS reads
+#pragma unroll
+        for (int i = 0; i < PPIECES; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // VMEM read (LDS-DMA)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - PPIECES * PER, 0);
+        dma_advance();
+        st_cur = st_cur == PSTAGES - 1 ? 0 : st_cur + 1;
+        st_new = st_new == PSTAGES - 1 ? 0 : st_new + 1;
+
+        if (++c_k < nk) continue;
+        // ---- the tile is complete: epilogue (the prefetch of the next tile's first k-steps is in flight meanwhile)
+        c_k = 0;
+        int bm, bn;
+        p288_tile_coords(seq_of(c_j), tiles_m, tiles_n, &bm, &bn);
+        ++c_j;
+        const int mw = bm * PBM + wm * (16 * PWI), nw = bn * PBN + wn * (16 * PWJ);
+        // one specialisation per (activation, residual, row-add) combination: the per-element switch on g.act would otherwise be
+        // compiled into 576 branchy copies
+        const int combo = g.act * 4 + (g.residual ? 2 : 0) + (g.rowadd ? 1 : 0);
+        switch (combo) {
+            case ACT_NONE * 4 + 0: p288_epilogue<ACT_NONE, false, false>(g, acc, stg, mw, nw, lane); break;
+            case ACT_NONE * 4 + 1: p288_epilogue<ACT_NONE, false, true>(g, acc, stg, mw, nw, lane); break;
+            case ACT_NONE * 4 + 2: p288_epilogue<ACT_NONE, true, false>(g, acc, stg, mw, nw, lane); break;
+            case ACT_GELU_TANH * 4 + 0: p288_epilogue<ACT_GELU_TANH, false, false>(g, acc, stg, mw, nw, lane); break;
+            case ACT_GELU_ERF * 4 + 0: p288_epilogue<ACT_GELU_ERF, false, false>(g, acc, stg, mw, nw, lane); break;
+            case ACT_QUICK_GELU * 4 + 0: p288_epilogue<ACT_QUICK_GELU, false, false>(g, acc, stg, mw, nw, lane); break;
+            default: p288_epilogue<-1, true, true>(g, acc, stg, mw, nw, lane); break;      // anything else: generic form
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
+}
+
+static int g_p288_cus = 0;
+extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_p288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        g_p288_cus = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int tiles_m = ceil_div(g->M, PBM), tiles_n = ceil_div(g->N, PBN), T = tiles_m * tiles_n;
+    int grid = T < g_p288_cus ? T : (g_p288_cus & ~7);            // several rounds: whole XCD groups (the locality order needs gridDim % 8 == 0)
+    hipLaunchKernelGGL(gemm_tile_p288_kernel, dim3(grid), dim3(512), PLDS_BYTES, st, *g, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+// what the shape must satisfy (the caller falls back to the other tile kernels otherwise)
+extern "C" int aha_gemm_tile_p288_ok(const GemmTileArgs* g) {
+    return (g->K % PBK) == 0 && g->K >= PBK && !(g->N & 7) && !(g->ldc & 7) && (!g->residual || !(g->ldr & 7)) &&
+           (!g->rowadd || !(g->ldra & 7)) && !(g->lda & 7) && !(g->ldw & 7);
+}
+// share of the chip's MFMA time the 288 x 256 decomposition of this shape uses: tile padding x round quantisation
+extern "C" float aha_gemm_tile_p288_efficiency(const GemmTileArgs* g, int n_cus) {
+    const int tiles_m = ceil_div(g->M, PBM), tiles_n = ceil_div(g->N, PBN), T = tiles_m * tiles_n;
+    const int grid = T < n_cus ? T : (n_cus & ~7);
+    const int rounds = ceil_div(T, grid);
+    return ((float)g->M * (float)g->N) / ((float)rounds * (float)n_cus * (float)(PBM * PBN));
+}
