@@ -98,6 +98,7 @@ hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);
 void aha_gemm_tile_set_epi(int on);
 void aha_gemm_tile_set_p288(int on);
+void aha_gemm_tile_p288_set_pipelined(int v);
 hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st);
 int aha_gemm_tile_p288_ok(const GemmTileArgs* g);
 float aha_gemm_tile_p288_efficiency(const GemmTileArgs* g, int n_cus);

@@ -52,9 +52,11 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
-    p.add_argument("--abi-allgather", action="store_true",
-                   help="also run the C-ABI collective (aha_allgather_scores: RCCL communicator from a unique id) and compare it with "
-                        "torch.distributed's; always on for a single rank under --force-dist")
+    p.add_argument("--abi-allgather", action="store_true", help="(default now; kept for old command lines)")
+    p.add_argument("--no-abi-allgather", action="store_true",
+                   help="skip the C-ABI collective (aha_allgather_scores: RCCL communicator from a unique id, compared with torch.distributed's "
+                        "result and timed); by default it runs whenever torch.distributed is up, its set-up fenced by a store-based agreement")
+    p.add_argument("--no-ref-geometry", action="store_true", help="skip the secondary datum on the reference-faithful geometry (so400m/14@384, Tf=49)")
     p.add_argument("--dry-run-collective", action="store_true",
                    help="launcher / rendezvous / all-gather plumbing only, on synthetic score rows: no GPU, no hot path, value = null")
     p.add_argument("--tile-dma", type=int, default=-1, help="experiment: force a tiled-GEMM variant in the vision tower")
@@ -336,7 +338,7 @@ def main():
                  max_vit_frames=128 if secondary else 32, max_positions=cfg.lm.max_position_embeddings)
     if a.tile_dma >= 0:
         rt.set_tuning("tile_dma", a.tile_dma)
-    want_cpu = (not a.no_cpu_baseline) and rank == 0 and world == 1
+    want_cpu = (not a.no_cpu_baseline) and rank == 0             # rank 0 only, at every world size (timed after the ranks have parted)
     w_cpu = {k: v.cpu() for k, v in w.items()} if want_cpu else None
     del w
     torch.cuda.empty_cache()
@@ -393,7 +395,7 @@ def main():
         dist_info = {"allgather_us": ag_us, "ranks_seen": ranks_seen(), "backend": "RCCL (torch.distributed nccl)" if a.backend == "nccl" else "gloo",
                      "rows_per_rank": F * B, "bytes_per_rank": F * B * 12}
         assert dist_info["ranks_seen"] == a.gpus
-        if a.backend == "nccl" and (a.abi_allgather or world == 1):
+        if a.backend == "nccl" and not a.no_abi_allgather:       # the C ABI's own RCCL communicator, by default at every world size
             dist_info["c_abi_allgather"] = abi_allgather_check(dist, rt, wl.scores_dev, rank, world, local)
     assert torch.isfinite(wl.scores_host).all()
 
@@ -438,6 +440,18 @@ def main():
     else:
         wl.close()
 
+    ref_datum = None
+    if secondary and not a.no_ref_geometry:
+        rt.close()
+        rt = None
+        torch.cuda.empty_cache()
+        ref_datum = ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, sync)
+    if rt is not None:
+        rt.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()                               # nothing below talks to another rank
+
     if rank == 0:
         total_frames = F * B * world * a.steps
         rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,", "static_1stream")
@@ -456,6 +470,7 @@ def main():
             "static_cache_batched_frames": static_batched,
             "sink_w2048": sink_datum,
             "eight_stream_sink": eight_datum,
+            "ref_so400m_384": ref_datum,
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
         }
         if want_cpu:
@@ -464,9 +479,43 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+
+
+def ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, sync):
+    """secondary: the same single-stream static-cache step on the REFERENCE-FAITHFUL geometry (models/arguments_live.py:22-24,
+    SURVEY.md fact 3): so400m/14@384 tower (26 layers, width 1152, 16 heads x 72, MLP 4304, 729 patches) + Qwen2-7B dims,
+    bilinear 27 -> 7 pooling = 49 tokens per frame.  Its own runtime and seeded weights; every encode and LM step timed."""
+    from aha_amd.config import preset
+    from aha_amd.runtime import Runtime
+    from aha_amd.synth import make_frames, make_weights
+    cfg = preset("ref")
+    F, tf = a.frames, cfg.frame_num_tokens
+    w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=True)
+    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max(tf + 35, 320), max_vit_frames=32, max_positions=cfg.lm.max_position_embeddings)
+    del w
+    torch.cuda.empty_cache()
+    frames = make_frames(F, cfg.vision.image_size, seed=3000).to(dev)
+    wl = Workload(rt, cfg, dev, 1, F, "static", a.window, a.sink, frames, prefix_ids, query_ids, main_stream, vit_stream)
+    wl.run(2)
+    sync()
+    steps = 5
+    t0 = time.perf_counter()
+    wl.run(steps)
+    sync()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(wl.scores_host).all()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        rt.visual_embed(frames)
+    e1.record()
+    e1.synchronize()
+    out = {"workload": f"configs[1] on the reference-faithful geometry: so400m/14@384 + Qwen2-7B dims, 1 stream, static KV cache, {F} frames/step, Tf={tf} tokens/frame",
+           "frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3, "vision_ms_per_32_frames": e0.elapsed_time(e1) / 3 / F * 32}
+    wl.close()
     rt.close()
-    if use_dist:
-        dist.destroy_process_group()
+    return out
 
 
 def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
@@ -483,10 +532,37 @@ def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
         if box[0] is None:
             return {"ok": False, "error": "aha_comm_unique_id failed: " + lib.aha_comm_last_error().decode()}
         idb = (C.c_ubyte * L.COMM_ID_BYTES).from_buffer_copy(box[0])
+        # ncclCommInitRank blocks until EVERY rank has joined, and a collective on a communicator that one rank failed to build
+        # never completes: both steps are fenced by an agreement through torch.distributed's key-value store (host side, with a
+        # timeout), so a rank that cannot go on makes all ranks skip the diagnostic instead of stalling them.
+        store = dist.distributed_c10d._get_default_store()
+
+        def agree(tag, ok_here, timeout_s=60.0):
+            store.set(f"aha_abi_{tag}_{rank}", "1" if ok_here else "0")
+            t_end = time.time() + timeout_s
+            for r in range(world):
+                key = f"aha_abi_{tag}_{r}"
+                while True:
+                    try:
+                        if store.check([key]):
+                            break
+                    except Exception:
+                        pass
+                    if time.time() > t_end:
+                        return False
+                    time.sleep(0.01)
+                if store.get(key) != b"1":
+                    return False
+            return True
+
+        if not agree("ready", True):
+            return {"ok": False, "error": "not every rank reached the C-ABI communicator set-up: skipped on all ranks"}
         comm = C.c_void_p()
         rc = lib.aha_comm_init_rank(idb, L.COMM_ID_BYTES, world, rank, local, C.byref(comm))
-        if rc != 0:
-            return {"ok": False, "error": lib.aha_comm_last_error().decode()}
+        if not agree("init", rc == 0):
+            if rc == 0:
+                lib.aha_comm_destroy(comm)
+            return {"ok": False, "error": (lib.aha_comm_last_error().decode() if rc != 0 else "aha_comm_init_rank failed on another rank")}
         rows = scores_dev.shape[0] * scores_dev.shape[1]
         loc = scores_dev.contiguous().view(rows, 3)
         glob = torch.empty((world, rows, 3), dtype=torch.float32, device=scores_dev.device)

@@ -1,9 +1,14 @@
-"""Per-shape sweep of the tiled-GEMM variants through the developer hook aha_dev_gemm_tile.
+"""Per-shape sweep of the tiled-GEMM variants through the developer hook aha_dev_gemm_tile (variant 12 = persistent 288x256 with
+the plain k-step loop, 13 = the same kernel with software-pipelined fragment reads).
 Weights cycle over 24 distinct buffers (a tower's worth), so they stream from HBM as in the real encode."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", "libaha_amd.so"))
 lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+_raw = lib.aha_dev_gemm_tile
+def dev_gemm(A, W, C, M, N, K, v, st):
+    lib.aha_gemm_tile_p288_set_pipelined(1 if v == 13 else 0)
+    return _raw(A, W, C, M, N, K, 12 if v == 13 else v, st)
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
 Ms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [576, 1152, 2304, 4608, 18432]
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
@@ -18,7 +23,7 @@ for M in Ms:
         ref, line = None, []
         for v in variants:
             C.zero_()
-            rc = lib.aha_dev_gemm_tile(A.data_ptr(), Ws[0].data_ptr(), C.data_ptr(), M, N, K, v, st)
+            rc = dev_gemm(A.data_ptr(), Ws[0].data_ptr(), C.data_ptr(), M, N, K, v, st)
             assert rc == 0, (v, rc)
             torch.cuda.synchronize()
             if ref is None:
@@ -26,12 +31,12 @@ for M in Ms:
                 exact = (ref.float() - (A.float() @ Ws[0].float().T)).abs().max().item()
             same = torch.equal(ref, C)
             for i in range(NW):
-                lib.aha_dev_gemm_tile(A.data_ptr(), Ws[i].data_ptr(), C.data_ptr(), M, N, K, v, st)
+                dev_gemm(A.data_ptr(), Ws[i].data_ptr(), C.data_ptr(), M, N, K, v, st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for r in range(2):
                 for i in range(NW):
-                    lib.aha_dev_gemm_tile(A.data_ptr(), Ws[i].data_ptr(), C.data_ptr(), M, N, K, v, st)
+                    dev_gemm(A.data_ptr(), Ws[i].data_ptr(), C.data_ptr(), M, N, K, v, st)
             e1.record(); e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (2 * NW)
             line.append(f"v{v}:{us:6.1f}{'' if same else '!'}")
