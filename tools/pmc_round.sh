@@ -1,17 +1,38 @@
 #!/bin/bash
-# HBM-traffic counters (separate FETCH_SIZE / WRITE_SIZE passes, MI355X_MICROARCH.md HBM section) for the kernels the bench
-# quotes rooflines for.  Two workloads, static cache: the headline step (1 stream: gemm_ws kernels) and the 8-stream step
-# (M = 288: gemm_wl kernels).  Known limit (round 2): rocprofv3 --pmc crashes (SIGSEGV inside the tool's dispatch interception)
-# or stalls on every run that uses an EVICTING cache policy, while --kernel-trace on the same commands works; the steady-state
-# sink kernels (attn_fwd / attn_lm at 2,048 keys, sink_rerotate) therefore have no PMC traffic figure (bench.py reports null).
-# Output: gpurun_out/round/pmc_hbm_traffic.json
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O; rm -rf $O/pmc_f $O/pmc_w
+# Counter passes of round 3 (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc runs, no tracing flags, the program
+# itself behind `--`).  Four workloads for the HBM-traffic summary bench.py reads (each row carries its workload):
+#   static_1stream       headline step (gemm_ws kernels, fused static attention)      bench.py --no-secondary
+#   static_8stream       M = 288 step (gemm_wl kernels)                                bench.py --streams 8 --no-secondary
+#   sink_1stream_steady  1 stream, SinkCache W=2048: evicts + re-rotates + attends over 2,048 keys   tools/diag/sink_steps.py 1
+#   sink_8stream_steady  8 streams of the same                                         tools/diag/sink_steps.py 8
+# and one SQ/GRBM pass for MFMA utilisation on the vision tower (4 layers, 32 frames) and on the 8-stream LM step.
+# Output: gpurun_out/round/pmc_hbm_traffic.json, pmc_mfma_vit32.json, pmc_mfma_lm8.json   (copy into profiles/r03_*)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O; rm -rf $O/pmc_*
 cd /tmp && export TMPDIR=/tmp
+run() {   # tag counter(s) program args...
+  local tag=$1 ctr=$2; shift 2
+  timeout -k 10 240 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_$tag -- "$@" > /dev/null 2> $O/pmc_$tag.err
+  local rc=$?; echo "PMC $tag rc=$rc"; [ $rc -eq 124 -o $rc -eq 137 ] && { echo "PMC $tag hit its limit: stopping"; exit 1; }
+  find $O/pmc_$tag -name "*counter_collection.csv" -size +40M -delete
+}
+B1="python3 $R/bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary"
+B8="python3 $R/bench.py --streams 8 --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary"
+S1="python3 $R/tools/diag/sink_steps.py 1 0 default_sink 120"
+S8="python3 $R/tools/diag/sink_steps.py 8 0 default_sink 120"
 for c in FETCH_SIZE WRITE_SIZE; do
-  d=$O/pmc_f; [ $c = WRITE_SIZE ] && d=$O/pmc_w
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $d/head -- python3 $R/bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_head_$c.err; echo "PMC $c head rc=$?"
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $d/b8 -- python3 $R/bench.py --streams 8 --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_b8_$c.err; echo "PMC $c 8-stream rc=$?"
+  x=f; [ $c = WRITE_SIZE ] && x=w
+  run s1_$x $c $B1; run s8_$x $c $B8; run k1_$x $c $S1; run k8_$x $c $S8
 done
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+run mfma_vit "$SQ" python3 $R/tools/diag/vit_only.py 1
+run mfma_lm8 "$SQ" $S8
 cd $R
-python tools/pmc_summary.py $O/pmc_f $O/pmc_w $O/pmc_hbm_traffic.json
-rm -rf $O/pmc_f $O/pmc_w
+python3 tools/pmc_summary.py $O/pmc_hbm_traffic.json \
+  "static_1stream=$O/pmc_s1_f,$O/pmc_s1_w,bench.py --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary" \
+  "static_8stream=$O/pmc_s8_f,$O/pmc_s8_w,bench.py --streams 8 --steps 1 --warmup 0 --frames 4 --no-cpu-baseline --no-secondary" \
+  "sink_1stream_steady=$O/pmc_k1_f,$O/pmc_k1_w,tools/diag/sink_steps.py 1 0 default_sink 120 (second half of each kernel's dispatches = cache full, evicting)" \
+  "sink_8stream_steady=$O/pmc_k8_f,$O/pmc_k8_w,tools/diag/sink_steps.py 8 0 default_sink 120 (second half of each kernel's dispatches)" > $O/pmc_hbm_traffic.txt
+tail -30 $O/pmc_hbm_traffic.txt
+python3 tools/pmc_mfma_summary.py $O/pmc_mfma_vit $O/pmc_mfma_vit32.json
+python3 tools/pmc_mfma_summary.py $O/pmc_mfma_lm8 $O/pmc_mfma_lm8.json
+rm -rf $O/pmc_s1_* $O/pmc_s8_* $O/pmc_k1_* $O/pmc_k8_* $O/pmc_mfma_vit $O/pmc_mfma_lm8
