@@ -48,7 +48,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the secondary data (sink_w2048, eight_stream_sink, static batching)")
     p.add_argument("--lm-priority", action="store_true", help="run the LM chain on a high-priority HIP stream")
-    p.add_argument("--no-overlap", action="store_true", help="encode and score on one stream (no ViT/LM overlap)")
+    p.add_argument("--overlap", action="store_true",
+                   help="encode batch k+1 on a second HIP stream while the LM scores batch k (round 3: measured 1.8 %% SLOWER than serial with "
+                        "the persistent tower kernels, which hold every CU for a whole GEMM; default off)")
+    p.add_argument("--no-overlap", action="store_true", help="(default now; kept for old command lines)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
@@ -254,6 +257,7 @@ def roofline_hbm(kernel, ms, n, by, traffic_prefix=None, workload=None):
 
 def main():
     a = parse()
+    a.no_overlap = not a.overlap
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)                                          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -348,8 +352,9 @@ def main():
     frames = [make_frames(F, cfg.vision.image_size, seed=1000 * rank + s).to(dev) for s in range(B)]
     frames_all = torch.cat(frames, 0)                              # [B*F,3,S,S] stream-major
 
-    # The vision tower is MFMA-bound, the LM steps are HBM-bound and they use disjoint workspaces, so
-    # the tower of batch k+1 runs on a second HIP stream while the LM scores batch k.  --no-overlap serialises them.
+    # The vision tower is MFMA-bound, the LM steps are HBM-bound and they use disjoint workspaces, so with --overlap the tower
+    # of batch k+1 runs on a second HIP stream while the LM scores batch k.  Default: one stream (the persistent tower kernels
+    # occupy every CU for a whole GEMM, so the LM's short kernels only queue behind them: profiles/r03_attn_splitwave_negative.txt).
     main_stream = torch.cuda.Stream(priority=-1) if a.lm_priority else torch.cuda.current_stream()   # LM chain: short kernels
     vit_stream = torch.cuda.Stream() if not a.no_overlap else main_stream
     if a.vit_cus > 0 and not a.no_overlap:

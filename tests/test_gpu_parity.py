@@ -977,6 +977,41 @@ def test_flash_attn2_static_mask_mode(which, request):
         sf.close(), sd.close()
 
 
+@pytest.mark.parametrize("policy", ["default_sink", "sliding_window"])
+def test_hf449_sdpa_mask_mode_on_evicting_caches(policy, tiny128):
+    """AHA_ATTN_HF449_SDPA: the mask arithmetic of the transformers version the reference pins (4.49, requirements.txt:57: key j
+    visible to new token i iff j <= L_before + i, mask sliced to the returned key length).  It equals the default while a cache
+    grows and departs from it once a SinkCache / SlidingWindowCache is full (a new token then sees later tokens of its own
+    chunk).  HIP path with that semantics vs the oracle run with it, every position's hidden state and head outputs, over
+    steps that fill the window and evict; and the two semantics do differ after the window is full (so the mode is live)."""
+    from oracle.qwen2_live import OracleLM
+    cfg, w, rt = tiny128
+    H = cfg.lm.hidden_size
+    W, S = 40, 6
+    o = OracleLM(cfg.lm, w, torch.bfloat16, attn_semantics="hf449_sdpa")
+    oc = _oracle_policy(policy, W, S)
+    sh = rt.open_stream(policy, W, S, attn_semantics="hf449_sdpa")
+    sd = rt.open_stream(policy, W, S)
+    g = torch.Generator().manual_seed(77)
+    differed = False
+    for step, T in enumerate([13, 9, 9, 9, 9, 5, 9, 9]):
+        x = (torch.randn(1, T, H, generator=g) * 0.5).bfloat16()
+        want = o.step(x, oc)
+        got_d = rt.lm_step([sd], x.cuda()).cpu()
+        got_h = rt.lm_step([sh], x.cuda()).cpu()
+        raw = rt.heads_all(1, T).cpu()
+        hid = rt.last_hidden_all(1, T).float().cpu()
+        assert sh.get_seq_length() == oc.get_seq_length()
+        assert torch.isfinite(raw).all()
+        assert (hid - want["hidden"].float()).abs().max().item() <= 0.12, (policy, step)
+        assert (raw[..., :2] - want["informative_logits"]).abs().max().item() <= 0.03, (policy, step)
+        assert (raw[..., 3:4] - want["uncertainty"]).abs().max().item() <= 0.03, (policy, step)
+        if sh.get_seq_length() == W and step >= 4:
+            differed = differed or not torch.equal(got_d, got_h)
+    assert differed, "the 4.49 mask arithmetic must depart from the default once the window is full"
+    sh.close(), sd.close()
+
+
 def test_timed_steps_bypass_graph_replay_and_lifetime_rules(tiny128):
     """(1) With a GEMM kind being timed a step is launched directly (a plain hipEventRecord issued during capture is not a
     graph node, so replayed steps would leave the events stale): two consecutive timed steps under use_graph = 1 both report
