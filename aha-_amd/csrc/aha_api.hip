@@ -304,6 +304,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "wl_bal") aha_gemm_wl_set_balanced(value);
     else if (k == "layer_first") c->layer_first = value;       // with layer_count: run decoder layers [first, first+count) only (parity taps)
     else if (k == "layer_count") c->layer_count = value;
+    else if (k == "rerot_pg") aha_sink_rerotate_set_pg(value);   // plane groups of the sink re-rotation kernel (0 = heuristic)
     else if (k == "fuse_static") c->fuse_static = value;
     else if (k == "static_attn") c->static_attn = value;
     else if (k == "pool_subset") c->pool_subset = value;

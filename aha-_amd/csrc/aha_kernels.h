@@ -112,6 +112,7 @@ hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo
 hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, hipStream_t st);   // sd_dev: DEVICE pointer
 hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, int T, bf16* out, int ldo, float scale, hipStream_t st);
+void aha_sink_rerotate_set_pg(int v);
 hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin, const bf16* cosb, const bf16* sinb, int layers, int Hkv, int D, hipStream_t st);
 hipError_t aha_cache_update_layer(const StreamStep* ss, int layer, int Hkv, int D, int T, const bf16* knew, const bf16* vnew, const bf16* rcos, const bf16* rsin, const bf16* cosb, const bf16* sinb, hipStream_t st);
 hipError_t aha_repetition_penalty(float* logits, int V, const long* hist, const int* n_hist, float penalty, float* tmp, hipStream_t st);

@@ -344,11 +344,15 @@ static __device__ __forceinline__ void rerot_coef4(const bf16* __restrict__ cosb
 
 // rcos_/rsin_ == nullptr: no (window, sink, T) table is registered - the coefficients come from the RoPE table (cosb/sinb) on
 // the fly, so the first evicting step of a stream allocates nothing and launches no table build.
+// A thread owns one (kept key, 4-channel group) and walks the (layer, kv head) planes blockIdx.y, blockIdx.y + gridDim.y, ..:
+// the coefficients depend on the key only, so they are fetched / computed ONCE per thread and the loop body is the K row's
+// 16 bytes in, 16 bytes out (four planes in flight) - HBM-bound on the 113 MB per stream-step it has to move.
+// grid: (key blocks, plane groups, B); block 256 threads = (256 / (D/8)) keys x D/8 items.
 template <int D>
 __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __restrict__ sdp, unsigned stream_mask,
                                                             const void* __restrict__ rcos_, const void* __restrict__ rsin_,
                                                             const void* __restrict__ cosb_, const void* __restrict__ sinb_,
-                                                            int layers, int Hkv) {
+                                                            int planes) {
     const bf16 *rcos = static_cast<const bf16*>(rcos_), *rsin = static_cast<const bf16*>(rsin_);
     constexpr int HALF = D / 2, IPK = HALF / 4, KPB = 256 / IPK;
     const int b = blockIdx.z;
@@ -358,8 +362,6 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
     if (key >= ss.n_rerot) return;
     const int d = (threadIdx.x % IPK) * 4;
     const int slot = phys_slot(ss, ss.n_fixed + key);
-    bf16* kp = ss.k_base + ((long)blockIdx.y * ss.cap + slot) * D + d;     // blockIdx.y = layer*Hkv + hk
-    const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
     bf16x4 c1, s1, c2, s2;
     if (rcos) {
         const long trow = (long)(ss.rerot_row0 + key) * D;
@@ -370,7 +372,27 @@ __global__ __launch_bounds__(256) void sink_rerotate_kernel(const StepDesc* __re
         rerot_coef4(cosb, sinb, D, ss.n_fixed, sdp->T, ss.rerot_row0 + key, d, &c1, &s1);
         rerot_coef4(cosb, sinb, D, ss.n_fixed, sdp->T, ss.rerot_row0 + key, d + HALF, &c2, &s2);
     }
-    rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
+    const long pstride = (long)ss.cap * D;                   // elements between consecutive (layer, kv head) planes
+    bf16* k0 = ss.k_base + (long)slot * D + d;
+    const int step = gridDim.y;
+    int p = blockIdx.y;
+    for (; p + 3 * step < planes; p += 4 * step) {           // four planes in flight per thread
+        bf16* kp[4];
+        bf16x4 x1[4], x2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kp[u] = k0 + (long)(p + u * step) * pstride;
+            x1[u] = *reinterpret_cast<const bf16x4*>(kp[u]);
+            x2[u] = *reinterpret_cast<const bf16x4*>(kp[u] + HALF);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rerotate_store4<HALF>(kp[u], x1[u], x2[u], c1, s1, c2, s2);
+    }
+    for (; p < planes; p += step) {
+        bf16* kp = k0 + (long)p * pstride;
+        const bf16x4 x1 = *reinterpret_cast<const bf16x4*>(kp), x2 = *reinterpret_cast<const bf16x4*>(kp + HALF);
+        rerotate_store4<HALF>(kp, x1, x2, c1, s1, c2, s2);
+    }
 }
 
 // Operator-level Cache.update of ONE layer (aha_cache_update): the same ring addressing and the same re-rotation arithmetic
@@ -713,15 +735,21 @@ hipError_t aha_qkv_finish_attn_static(const QkvFinishArgs* a, const StepDesc* sd
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+static int g_rerot_pg = 0;       // tuning "rerot_pg": plane groups of sink_rerotate_kernel (0 = heuristic)
+void aha_sink_rerotate_set_pg(int v) { g_rerot_pg = v; }
 hipError_t aha_sink_rerotate(const StepDesc* sd_dev, unsigned stream_mask, int n_streams, int nmax, const bf16* rcos, const bf16* rsin,
                              const bf16* cosb, const bf16* sinb, int layers, int Hkv, int D, hipStream_t st) {
     if (nmax == 0 || stream_mask == 0) return hipSuccess;
+    const int planes = layers * Hkv;
+    int pg = planes < 8 ? planes : 8;                        // plane groups: each thread walks planes / pg planes with one set of coefficients
+    if (n_streams >= 4 && planes >= 4) pg = 4;               // enough workgroups from the streams alone
+    if (g_rerot_pg > 0) pg = g_rerot_pg < planes ? g_rerot_pg : planes;
     if (D == 64) {
         const int kpb = 256 / (64 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<64>), dim3(ceil_div(nmax, kpb), pg, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers * Hkv);
     } else if (D == 128) {
         const int kpb = 256 / (128 / 8);
-        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), layers * Hkv, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers, Hkv);
+        hipLaunchKernelGGL((sink_rerotate_kernel<128>), dim3(ceil_div(nmax, kpb), pg, n_streams), dim3(256), 0, st, sd_dev, stream_mask, rcos, rsin, cosb, sinb, layers * Hkv);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
