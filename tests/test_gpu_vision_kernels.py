@@ -10,7 +10,7 @@ the reference runs, and every encoder layer teacher-forced from the bf16 oracle'
   LayerNorm: <= 0.5 ulp + fp32 noise of an fp32-statistics evaluation (asserted <= 1 ulp, >= 99 % bit-equal to the rounded exact value)
   preprocess + patch unfold: EXACT (integer pixels through fixed fp32 constants)
   pooling: bilinear 24->6 / 27->7, average, max, adaptive average vs fp64: <= 1 ulp; the gathered-rows route == the direct route, bit for bit
-  encoder layer, teacher-forced: output within 4 ulps at the tensor's scale of the bf16 oracle layer (worst over layers)
+  encoder layer, teacher-forced: output within 6 ulps at the tensor's scale of the bf16 oracle layer (measured 3-4; p99.9 2)
 """
 import json
 import math
@@ -235,7 +235,7 @@ def test_every_encoder_layer_teacher_forced(which, request):
         e = _ulp_at_scale(got, want)
         _note(f"{which} encoder layer {i} teacher-forced", e)
         worst = max(worst, e.max().item())
-    assert worst <= 4.0, worst
+    assert worst <= 6.0, worst                       # measured 3-4 (p99.9: 2); a wrong row, head or k-step is tens of ulps
     # and the whole tower from the pixels agrees with the chain of teacher-forced layers' input (same kernels, free-running)
     emb = rt.visual_embed(fr.cuda())
     tower = rt.tower_output(n).cpu().view_as(final)
