@@ -1,0 +1,521 @@
+// C ABI, part 3: token embedding, the LM step (aha_lm_step: planning, descriptor upload, the layer loop, HIP-graph replay) and
+// the reads of its results.
+#include "api_internal.h"
+
+extern "C" int aha_embed_tokens(aha_ctx* c, const int64_t* ids, int n, void* out, aha_hip_stream st) {
+    if (!c || !ids || !out) return AHA_E_INVAL;
+    if (!c->embed) return fail(c, AHA_E_NOENT, "model.embed_tokens.weight was not loaded");
+    HIPCHK(c, aha_embed_gather((const long*)ids, n, c->embed, c->d.hidden, c->d.vocab, (bf16*)out, c->d.hidden, (hipStream_t)st));
+    return 0;
+}
+
+// --------------------------------------------------------------------------------------------
+// LM step
+// --------------------------------------------------------------------------------------------
+int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave) {
+    (void)M;                                  // S must NOT depend on M: a batched step stays bit-identical to solo steps
+    const int nc = w.KS / 8;                  // slices are placed in units of 8 k-steps (gemm_ws.hip), independent of KC
+    int S = c->split[kind];
+    if (S <= 0) {
+        // ~2 four-wave workgroups per CU.  (One per CU - O 8 -> 4, QKV 7 -> 3, fewer slabs for the reducing kernels - measured
+        // ~1 % faster on the single-stream step but 3-5 % slower on the batched shapes, which run 8-wave workgroups and were left
+        // under-filled; S may not depend on M, so the batched-friendly value stays.)
+        const int nblk = ceil_div(w.n_tiles, c->wpb[kind] * nt_per_wave);
+        S = 512 / (nblk > 0 ? nblk : 1);
+        if (S > 8) S = 8;
+    }
+    if (S > nc) S = nc;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    return S;
+}
+
+GemmWsArgs ws_args(const bf16* X, int ldx, int M, int m0, int mrows, const PackedW& w, int S, float* partial, int ldp, bf16* out,
+                          int ldo, float* outf, int ldof) {
+    GemmWsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X + (long)m0 * ldx; a.ldx = ldx; a.M = mrows;
+    a.Wp = w.p; a.KS = w.KS; a.Kx = w.K; a.n_tiles = w.n_tiles; a.S = S;
+    a.partial = partial ? partial + (long)m0 * ldp : nullptr; a.ldp = ldp; a.slab_stride = (long)M * ldp;
+    a.out = out ? out + (long)m0 * ldo : nullptr; a.ldo = ldo;
+    a.outf = outf ? outf + (long)m0 * ldof : nullptr; a.ldof = ldof;
+    a.bias = nullptr; a.N = w.N;
+    return a;
+}
+
+// Row chunking and kernel choice of the weight-streaming GEMMs.  M <= 128: gemm_ws (weights in registers).  Above that the
+// mid-M kernel (gemm_wl.hip: both operands through LDS-DMA stages) takes chunks of up to 320 rows; both kernels sum every
+// output element's k-steps in the same order with the same split-K slices, so the choice never changes a bit.
+int ws_row_chunk(const aha_ctx* c, int epi, int M, int K) {
+    const bool wl_ok = c->use_wl && M > 128 && (epi == EPI_PARTIAL || epi == EPI_SWIGLU) && K % 32 == 0;
+    if (!wl_ok) return aha_gemm_ws_max_m(epi);
+    // even chunks of whole row tiles, so that every chunk of an M > 128 step stays in the mid-M kernel's range (129..320)
+    const int n = ceil_div(M, 320);
+    return round_up(ceil_div(M, n), 16);
+}
+// Every row chunk of this GEMM runs gemm_wl (what a k-blocked operand layout needs: gemm_ws reads row-major X only).
+bool ws_all_wl(const aha_ctx* c, int epi, int M, int K) {
+    if (!(c->use_wl && M > 128 && (epi == EPI_PARTIAL || epi == EPI_SWIGLU) && K % 32 == 0)) return false;
+    const int mmax = ws_row_chunk(c, epi, M, K);
+    for (int m0 = 0; m0 < M; m0 += mmax) {
+        const int rows = (M - m0 < mmax) ? M - m0 : mmax;
+        if (rows <= 128 || rows > 320) return false;
+    }
+    return true;
+}
+hipError_t ws_or_wl(const aha_ctx* c, const GemmWsArgs* a, int epi, int wpb, hipStream_t st) {
+    if (c->use_wl && aha_gemm_wl_supports(a, epi)) return aha_gemm_wl(a, epi, st);
+    return aha_gemm_ws(a, epi, wpb, st);
+}
+
+// HIP-event bracket of one timed launch group (tuning "time_gemm": bit k = kind k), on the launch stream
+static int timed_begin(aha_ctx* c, int kind, hipStream_t st) {
+    if ((int)c->ev[kind].size() <= c->ev_used[kind]) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev[kind].push_back({a, b});
+    }
+    HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].first, st));
+    return 0;
+}
+static int timed_end(aha_ctx* c, int kind, double bytes, hipStream_t st) {
+    HIPCHK(c, hipEventRecord(c->ev[kind][c->ev_used[kind]].second, st));
+    c->ev_used[kind]++;
+    c->gk_bytes[kind] += bytes;
+    return 0;
+}
+
+int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp,
+                   bf16* out, int ldo, float* outf, int ldof, hipStream_t st, int kb) {
+    // kb bit 0: X is k-blocked ([K/32][M][32], gemm_wl.hip); bit 1: the SwiGLU output is written k-blocked.  Callers set them
+    // only when ws_all_wl() holds for the GEMMs on both sides of the buffer.
+    const int mmax = ws_row_chunk(c, epi, M, w.K);
+    const bool timed = kind >= 0 && ((c->time_gemm >> kind) & 1);      // time_gemm: bit k = GEMM kind k
+    if (timed) { if (int rc = timed_begin(c, kind, st)) return rc; }
+    for (int m0 = 0; m0 < M; m0 += mmax) {
+        GemmWsArgs a = ws_args(X, ldx, M, m0, (M - m0 < mmax) ? M - m0 : mmax, w, S, partial, ldp, out, ldo, outf, ldof);
+        if (kb & 1) { a.X = X + (long)m0 * 32; a.xkb = M; }
+        if (kb & 2) { a.out = out + (long)m0 * 32; a.okb = M; }
+        HIPCHK(c, ws_or_wl(c, &a, epi, kind >= 0 ? c->wpb[kind] : 4, st));
+    }
+    if (timed) { if (int rc = timed_end(c, kind, w.bytes() * ceil_div(M, mmax), st)) return rc; }
+    c->last_weight_bytes += w.bytes();
+    c->last_flops += 2.0 * (double)w.n_tiles * 16.0 * (double)w.K * (double)M;
+    return 0;
+}
+
+extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
+                           float* out_raw, void* out_last_hidden, aha_hip_stream st_) {
+    if (!c || !streams || !embeds) return AHA_E_INVAL;
+    if (!c->weights_loaded) return fail(c, AHA_E_INVAL, "weights not loaded");
+    if (!c->rope_cos) return fail(c, AHA_E_INVAL, "rope table not set");
+    if (B <= 0 || B > AHA_MAX_B) return fail(c, AHA_E_RANGE, "B out of range (1..16)");
+    if (T <= 0 || B * T > c->d.max_step_tokens) return fail(c, AHA_E_RANGE, "B*T > max_step_tokens");
+    hipStream_t st = (hipStream_t)st_;
+    const aha_model_desc& d = c->d;
+    const int H = d.hidden, Dh = d.head_dim, QD = d.heads * Dh, I = d.inter, M = B * T, G = d.heads / d.kv_heads;
+
+    // ---- plan (host bookkeeping only; validate everything before mutating any stream)
+    for (int b = 0; b < B; ++b) {
+        aha_stream* s = streams[b];
+        if (!s || s->ctx != c) return fail(c, AHA_E_INVAL, "bad stream handle");
+        if (s->poisoned) return fail(c, AHA_E_INVAL, "stream state is undefined after a failed step (keys were re-rotated / slots overwritten): call aha_stream_reset");
+        for (int b2 = 0; b2 < b; ++b2)
+            if (streams[b2] == s && !(s->policy == AHA_CACHE_STATIC && s->len > 0))
+                return fail(c, AHA_E_INVAL, "a stream may appear only once per step (except a frozen TrulyStaticCache stream, whose "
+                                            "step neither reads nor writes per-step state: its frames are independent)");
+    }
+    StepDesc sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.B = B;
+    sd.T = T;
+    // Host bookkeeping is advanced by plan_stream BEFORE any device work is enqueued; this guard puts every stream back
+    // if anything fails before the first destructive launch (planning, descriptor upload), so a caller may retry.  Once
+    // device work that changes the caches has been enqueued (in-place re-rotation of kept keys, ring slots overwritten by
+    // the K/V append) a retry would rotate the kept keys a second time: the streams are then marked poisoned instead of
+    // rolled back and refuse further steps until aha_stream_reset.
+    struct Rollback {
+        aha_stream* const* streams; int n = 0; int saved[AHA_MAX_B][3]; bool armed = true, destructive = false;
+        ~Rollback() {
+            if (!armed) return;
+            for (int b = n - 1; b >= 0; --b) {
+                if (destructive) { streams[b]->poisoned = true; continue; }
+                streams[b]->len = saved[b][0]; streams[b]->head = saved[b][1]; streams[b]->seen = saved[b][2];
+            }
+        }
+    } guard{streams};
+    for (int b = 0; b < B; ++b) {
+        aha_stream* s = streams[b];
+        guard.saved[b][0] = s->len; guard.saved[b][1] = s->head; guard.saved[b][2] = s->seen;
+        guard.n = b + 1;
+        int rc = plan_stream(c, s, T, &sd.s[b]);
+        if (!rc && sd.s[b].pos_base + T > c->n_pos) rc = fail(c, AHA_E_RANGE, "position exceeds the RoPE table");
+        if (rc) return rc;
+    }
+    ORDER_LM(c, st);
+    // SinkCache re-rotation (test/sink_cache.py:35-55): sink_rerotate_kernel computes the coefficients from the RoPE table on the
+    // fly unless the caller registered a (window, n_sink, T) table (aha_ctx_set_rerotation_table) - nothing is allocated or built
+    // inside a per-frame call.  The rows it reads are RoPE positions sink .. window - 1.
+    for (int b = 0; b < B; ++b)
+        if (sd.s[b].n_rerot > 0 && streams[b]->W > c->n_pos) return fail(c, AHA_E_RANGE, "SinkCache window exceeds the RoPE table");
+    c->last_weight_bytes = c->last_kv_bytes = c->last_flops = 0;
+    for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
+
+    // ---- SinkCache re-rotation of kept keys (all layers, one launch per distinct table)
+    int max_lk = 0;
+    for (int b = 0; b < B; ++b) {
+        max_lk = sd.s[b].len_after > max_lk ? sd.s[b].len_after : max_lk;
+        c->last_kv_bytes += (double)sd.s[b].len_after * d.layers * d.kv_heads * Dh * 2 * 2;
+    }
+    {
+        // Upload this step's descriptor (pinned ring slot -> the one device copy; stream order keeps the previous step's
+        // kernels ahead of the overwrite).  A slot is rewritten only after the upload that last read it has completed:
+        // an event recorded behind each upload is waited on before reuse - free when the caller synchronises every step,
+        // and a real wait only for a caller that runs more than SD_SLOTS steps ahead of the GPU.
+        const int si = c->sd_slot;
+        StepDesc* slot = c->sd_pin + si;
+        c->sd_slot = (si + 1) % aha_ctx::SD_SLOTS;
+        if (c->sd_ev[si]) HIPCHK(c, hipEventSynchronize(c->sd_ev[si]));
+        else HIPCHK(c, hipEventCreateWithFlags(&c->sd_ev[si], hipEventDisableTiming));
+        *slot = sd;
+        HIPCHK(c, hipMemcpyAsync(c->sd_dev, slot, sizeof(StepDesc), hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->sd_ev[si], st));
+        // streams sharing (W, sink) share the table; one launch per group, selected by a stream mask
+        bool done[AHA_MAX_B] = {false};
+        for (int b = 0; b < B; ++b) {
+            if (done[b] || sd.s[b].n_rerot == 0) continue;
+            unsigned mask = 0;
+            int nmax = 0;
+            for (int b2 = 0; b2 < B; ++b2) {
+                const bool same = sd.s[b2].n_rerot > 0 && streams[b2]->W == streams[b]->W && streams[b2]->sink == streams[b]->sink;
+                if (same) {
+                    done[b2] = true;
+                    mask |= 1u << b2;
+                    nmax = sd.s[b2].n_rerot > nmax ? sd.s[b2].n_rerot : nmax;
+                }
+            }
+            std::pair<bf16*, bf16*> tb{nullptr, nullptr};
+            if (auto it = c->rerot.find(std::make_tuple(streams[b]->W, streams[b]->sink, T)); it != c->rerot.end()) tb = it->second;
+            const bool timed = (c->time_gemm >> GK_REROT) & 1;
+            if (timed) { if (int rc = timed_begin(c, GK_REROT, st)) return rc; }
+            guard.destructive = true;
+            HIPCHK(c, aha_sink_rerotate(c->sd_dev, mask, B, nmax, tb.first, tb.second, c->rope_cos, c->rope_sin, d.layers, d.kv_heads, Dh, st));
+            if (timed) {
+                double by = 0;                               // algorithmic: every kept key of every layer read and written once
+                for (int b2 = 0; b2 < B; ++b2)
+                    if ((mask >> b2) & 1u) by += (double)sd.s[b2].n_rerot * d.layers * d.kv_heads * Dh * 2.0 * 2.0;
+                if (int rc = timed_end(c, GK_REROT, by, st)) return rc;
+            }
+        }
+    }
+
+    // attention geometry (launch shape only: the kernels read the key counts from the device descriptor)
+    int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
+    int n_splits = ceil_div(max_lk, split_len);
+    if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
+    if (n_splits < 1) n_splits = 1;
+
+    // Every stream of the step a frozen TrulyStaticCache: the new tokens' K/V are neither stored nor read
+    // (test/static_cache.py:33-36).  By default the full q|k|v projection still runs, as in the reference (its K/V columns
+    // are dead work, but the headline streams what the reference streams).  Experiments: fuse_static = 2 projects only the
+    // q tiles (they come first in the packed weight; same split, bit-identical q; -0.7 % step time); fuse_static = 1 also
+    // builds Q inside the attention kernel instead of launching qkv_finish (measured slower).
+    bool all_static_frozen = true;
+    for (int b = 0; b < B; ++b) all_static_frozen = all_static_frozen && sd.s[b].write_base < 0;
+    const bool q_only = all_static_frozen && c->fuse_static != 0;
+    const bool frozen_all = all_static_frozen && c->fuse_static == 1;
+    // ... and with a short frozen prefix (configs[1]: the 20-token query turn) qkv_finish and the attention are one launch on the
+    // vector ALUs (elementwise.hip: qkv_finish_attn_static_kernel; tuning "static_attn", on by default)
+    const bool static_attn = all_static_frozen && !frozen_all && c->static_attn && max_lk <= 64 && G <= 8;
+
+    // Everything from the first RMSNorm to the heads, on stream `st`, scores to `scores_out`: run directly, or recorded
+    // into a HIP graph (below).
+    int l_first = 0, l_end = d.layers;
+    if (c->layer_count > 0) {
+        l_first = c->layer_first < 0 ? 0 : (c->layer_first >= d.layers ? d.layers - 1 : c->layer_first);
+        l_end = l_first + c->layer_count > d.layers ? d.layers : l_first + c->layer_count;
+    }
+    // layout of the SwiGLU activation this step leaves in c->act (a function of M and the tunings only, so a replayed graph
+    // agrees with it): k-blocked when both MLP GEMMs run the mid-M kernel on every row chunk (the fused MLP block needs M <= 64)
+    c->act_kb_rows = (c->act_kb && I % 32 == 0 && ws_all_wl(c, EPI_SWIGLU, M, H) && ws_all_wl(c, EPI_PARTIAL, M, I)) ? M : 0;
+    auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
+        // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
+        HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
+
+        int rc;
+        for (int l = l_first; l < l_end; ++l) {
+            const LayerW& w = c->L[l];
+            // QKV projection -> split-K slabs (q tiles only for an all-frozen step, see above)
+            PackedW wq = w.qkv;
+            if (q_only) { wq.n_tiles = QD / 16; wq.N = QD; }
+            const int nq_ld = w.qkv.n_tiles * 16;
+            const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);      // same split as the full projection: bit-identical q
+            if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
+            AttnArgs a;
+            memset(&a, 0, sizeof(a));
+            if (static_attn) {
+                QkvFinishArgs qa;
+                memset(&qa, 0, sizeof(qa));
+                qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+                qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+                qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+                const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
+                if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
+                HIPCHK(c, aha_qkv_finish_attn_static(&qa, c->sd_dev, M, T, c->attn_out, QD, 1.0f / sqrtf((float)Dh), st));
+                if (t_attn) {
+                    double by = 0;
+                    for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;
+                    if ((rc = timed_end(c, GK_ATTN, by, st))) return rc;
+                }
+            } else {
+            if (!frozen_all) {
+                QkvFinishArgs qa;
+                memset(&qa, 0, sizeof(qa));
+                qa.partial = c->partial; qa.S = Sq; qa.slab_stride = (long)M * nq_ld; qa.ldp = nq_ld; qa.bias = w.qkv_bias;
+                qa.rope_cos = c->rope_cos; qa.rope_sin = c->rope_sin; qa.n_pos = c->n_pos;
+                qa.q_rot = c->q_rot; qa.ldq = QD; qa.Hq = d.heads; qa.Hkv = d.kv_heads; qa.D = Dh; qa.layer = l;
+                HIPCHK(c, aha_qkv_finish(&qa, c->sd_dev, M, st));
+            } else {
+                a.q_partial = c->partial; a.q_S = Sq; a.q_slab_stride = (long)M * nq_ld; a.q_ldp = nq_ld; a.q_bias = w.qkv_bias;
+                a.rope_cos = c->rope_cos; a.rope_sin = c->rope_sin; a.n_pos = c->n_pos;
+            }
+            // attention over the stream caches
+            a.q = c->q_rot; a.q_bs = (long)T * QD; a.ldq = QD;
+            a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
+            a.part_o = c->part_o; a.part_ml = c->part_ml;
+            a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
+            a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
+            const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
+            if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
+            HIPCHK(c, aha_attention(&a, c->sd_dev, B, Dh, st));
+            if (t_attn) {                                    // algorithmic: this layer's K and V of every stream read once
+                double by = 0;
+                for (int b = 0; b < B; ++b) by += (double)sd.s[b].len_after * d.kv_heads * Dh * 2.0 * 2.0;
+                if ((rc = timed_end(c, GK_ATTN, by, st))) return rc;
+            }
+            }
+            // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
+            const int So = pick_split(c, GK_O, w.o, M, 1);
+            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+            ResidNormArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
+            ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
+            const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
+            // One launch for resid_norm + gate/up + down (lm_fused.hip) when the step is a single small row block and both GEMM
+            // phases fit one workgroup per CU; otherwise (and while a GEMM kind is being timed) three launches.  c->partial is
+            // shared safely: o_proj's slabs are read in phase A, down's are written in phase C, two grid barriers later.
+            const int gu_blocks = ceil_div(w.gateup.n_tiles, 16), dn_blocks = ceil_div(w.down.n_tiles, 8) * Sd;
+            const bool fuse = c->fuse_mlp && M <= 64 && !c->time_gemm && c->wpb[GK_GATEUP] == 8 && c->wpb[GK_DOWN] == 8 &&
+                              gu_blocks <= c->n_cus && dn_blocks <= c->n_cus && M <= c->n_cus;
+            if (fuse) {
+                MlpBlockArgs mb;
+                memset(&mb, 0, sizeof(mb));
+                mb.rn = ra; mb.M = M;
+                mb.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
+                mb.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
+                mb.ctr = c->bar_ctr; mb.base = c->bar_base; mb.err = c->bar_err; mb.sc1 = c->fuse_mlp >= 2;
+                const int grid = c->n_cus < 256 ? c->n_cus : 256;
+                HIPCHK(c, aha_lm_mlp_block(&mb, grid, st));
+                c->bar_base += (unsigned long long)aha_lm_mlp_block_counter_step(grid);
+                c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
+                c->last_flops += 2.0 * 16.0 * M * ((double)w.gateup.n_tiles * w.gateup.K + (double)w.down.n_tiles * w.down.K);
+            } else {
+                // Between mid-M kernels the operands travel k-blocked ([K/32][M][32]): the consumer's LDS-DMA then pulls
+                // contiguous 1-KiB panels instead of 16 half cache lines per instruction (-16 % on down at M = 288; same bits).
+                // Here: the normed input of gate/up (xkb) and the SwiGLU activation for down_proj (akb).
+                const bool akb = c->act_kb_rows != 0, xkb = akb && c->act_kb >= 2 && H % 32 == 0;
+                ra.xkb = xkb ? M : 0;
+                HIPCHK(c, aha_resid_norm(&ra, M, st));
+                ra.xkb = 0;
+                // gate/up with fused SwiGLU epilogue
+                if ((rc = ws_gemm(c, GK_GATEUP, c->xn, H, M, w.gateup, EPI_SWIGLU, 1, nullptr, 0, c->act, I, nullptr, 0, st, (akb ? 2 : 0) | (xkb ? 1 : 0)))) return rc;
+                // down_proj -> slabs ; reduce + residual + next RMSNorm (next layer's input norm or model.norm)
+                if ((rc = ws_gemm(c, GK_DOWN, c->act, I, M, w.down, EPI_PARTIAL, Sd, c->partial, H, nullptr, 0, nullptr, 0, st, akb ? 1 : 0))) return rc;
+            }
+            ra.S = Sd;
+            ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
+            HIPCHK(c, aha_resid_norm(&ra, M, st));
+        }
+        // ---- heads on the last token of every stream
+        if (scores_out || out_raw) HIPCHK(c, aha_heads(c->xn, H, T - 1, T, B, c->heads_w, H, scores_out, out_raw, c->bar_err, st));
+        if (out_last_hidden)
+            HIPCHK(c, hipMemcpy2DAsync(out_last_hidden, (size_t)H * 2, c->xn + (size_t)(T - 1) * H, (size_t)T * H * 2, (size_t)H * 2, B,
+                                       hipMemcpyDeviceToDevice, st));
+
+        return 0;
+    };
+
+    // ---- residual stream <- embeds
+    HIPCHK(c, hipMemcpyAsync(c->h, embeds, (size_t)M * H * 2, hipMemcpyDeviceToDevice, st));
+
+    // ---- HIP-graph replay.  A step is ~230 launches; the host needs ~9 us per launch (2.8 ms per step, 88 % of the GPU time
+    // of a static step) and falls behind the GPU in the run of short kernels.  The per-step stream state lives in the device
+    // descriptor, so the recorded launches depend only on the launch geometry: batch, tokens, key-split shape, the
+    // frozen-static flags and the tuning epoch.  One captured graph therefore serves every step of that shape - any cache
+    // policy, any stream - and is replayed; it is captured on a private stream the second time a shape is seen (every lazily
+    // set kernel attribute has been set by then); any failure falls back to direct launches for that shape.  The descriptor
+    // upload, the sink re-rotation and the input / score copies stay outside the graph.
+    // from here on the launches overwrite ring slots; where a stream evicts this step, a failure can no longer be rolled back
+    for (int b = 0; b < B; ++b)
+        if (sd.s[b].write_base >= 0 && guard.saved[b][0] + sd.s[b].write_count > sd.s[b].len_after) guard.destructive = true;
+    const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
+    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0);
+    // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
+    // does not become a graph node, so a replay would leave the events holding stale timestamps.)
+    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->fuse_mlp && !c->time_gemm) {
+        aha_ctx::GraphEntry* ge = nullptr;
+        for (auto& g : c->graphs)
+            if (g.B == B && g.T == T && g.epoch == c->tune_epoch && g.n_splits == n_splits && g.split_len == split_len && g.flags == gflags) {
+                ge = &g;
+                break;
+            }
+        if (!ge) {
+            if (c->graphs.size() >= 64) {                    // more shapes than a 32k-token growing cache sweeps through (~44)
+                // drop the oldest shape; its executable may in principle still be queued, so it is only retired here and
+                // destroyed behind a device synchronisation once a few have piled up (rare), or with the context
+                if (c->graphs.front().exec) c->retired_graphs.push_back(c->graphs.front().exec);
+                c->graphs.erase(c->graphs.begin());
+                if (c->retired_graphs.size() >= 16) {
+                    HIPCHK(c, hipDeviceSynchronize());
+                    for (auto e : c->retired_graphs) hipGraphExecDestroy(e);
+                    c->retired_graphs.clear();
+                }
+            }
+            c->graphs.emplace_back();
+            ge = &c->graphs.back();
+            ge->B = B; ge->T = T; ge->epoch = c->tune_epoch; ge->n_splits = n_splits; ge->split_len = split_len; ge->flags = gflags;
+        }
+        if (!ge->exec && !ge->failed && ge->seen >= 1) {
+            hipGraph_t graph = nullptr;
+            bool ok = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok) {
+                const int brc = layers_and_heads(c->cap_stream, c->graph_scores);
+                const hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+                ok = brc == 0 && e == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) hipGraphDestroy(graph);
+            if (!ok) { ge->exec = nullptr; ge->failed = true; (void)hipGetLastError(); }
+            ge->wb = c->last_weight_bytes; ge->fl = c->last_flops;       // what the recorded launches stream / compute
+            for (int k = 0; k < GK_COUNT; ++k) { ge->ev_used[k] = c->ev_used[k]; ge->gk_bytes[k] = c->gk_bytes[k]; }
+            c->last_weight_bytes = c->last_flops = 0;                    // the capture executed nothing
+            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }
+        }
+        ge->seen++;
+        if (ge->exec) {
+            HIPCHK(c, hipGraphLaunch(ge->exec, st));
+            HIPCHK(c, hipMemcpyAsync(out_scores, c->graph_scores, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+            c->last_weight_bytes = ge->wb; c->last_flops = ge->fl + attn_flops;
+            for (int k = 0; k < GK_COUNT; ++k) { c->ev_used[k] = 0; c->gk_bytes[k] = 0; }   // a replay records no GEMM events (time_gemm steps are launched directly)
+            c->last_B = B;
+            c->last_T = T;
+            guard.armed = false;
+            return 0;
+        }
+    }
+    if (const int brc = layers_and_heads(st, out_scores)) return brc;
+    c->last_flops += attn_flops;
+    c->last_B = B;
+    c->last_T = T;
+    guard.armed = false;
+    return 0;
+}
+
+extern "C" int aha_lm_heads_all(aha_ctx* c, float* out_raw, aha_hip_stream st) {
+    if (!c || !out_raw || c->last_B == 0) return AHA_E_INVAL;
+    ORDER_LM(c, (hipStream_t)st);
+    HIPCHK(c, aha_heads(c->xn, c->d.hidden, 0, 1, c->last_B * c->last_T, c->heads_w, c->d.hidden, nullptr, out_raw, c->bar_err, (hipStream_t)st));
+    return 0;
+}
+
+extern "C" int aha_lm_last_hidden_all(aha_ctx* c, void* out, aha_hip_stream st) {
+    if (!c || !out || c->last_B == 0) return AHA_E_INVAL;
+    ORDER_LM(c, (hipStream_t)st);
+    HIPCHK(c, hipMemcpyAsync(out, c->xn, (size_t)c->last_B * c->last_T * c->d.hidden * 2, hipMemcpyDeviceToDevice, (hipStream_t)st));
+    return 0;
+}
+
+extern "C" int aha_lm_logits_last(aha_ctx* c, float* logits, int64_t* argmax, aha_hip_stream st_) {
+    if (!c || c->last_B == 0) return AHA_E_INVAL;
+    if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    const int B = c->last_B, T = c->last_T, H = c->d.hidden, V = c->d.vocab;
+    float* lg = logits ? logits : c->logits;
+    // last-token rows are strided by T*H in xn: ldx = T*H makes them the M = B rows of the GEMM
+    int rc = ws_gemm(c, -1, c->xn + (size_t)(T - 1) * H, T * H, B, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, lg, V, st);
+    if (rc) return rc;
+    if (argmax) HIPCHK(c, aha_argmax(lg, V, V, B, (long*)argmax, st));
+    return 0;
+}
+
+// all-position lm_head of the last step: outputs.logits [B,T,V] of the reference forward
+// (video_head_live_llava_qwen.py:175), fp32, row-chunked through the weight-streaming GEMM
+extern "C" int aha_lm_logits_all(aha_ctx* c, float* logits, aha_hip_stream st_) {
+    if (!c || !logits || c->last_B == 0) return AHA_E_INVAL;
+    if (!c->lm_head.p) return fail(c, AHA_E_NOENT, "lm_head.weight was not loaded");
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    const int M = c->last_B * c->last_T, H = c->d.hidden, V = c->d.vocab;
+    return ws_gemm(c, -1, c->xn, H, M, c->lm_head, EPI_F32_RBF, 1, nullptr, 0, nullptr, 0, logits, V, st);
+}
+
+// parity tap: copy a workspace of the last aha_lm_step.  which: 0 residual stream h [M][hidden] (= the hidden state after the
+// last executed decoder layer), 1 xn [M][hidden] (h normalised for the next layer / by model.norm), 2 rotated queries
+// [M][heads*head_dim], 3 attention output [M][heads*head_dim], 4 SwiGLU activation [M][inter]; the last three hold the LAST
+// executed layer's values (tuning layer_first / layer_count select it).
+extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream st_) {
+    if (!c || !out || c->last_B == 0) return AHA_E_INVAL;
+    hipStream_t st = (hipStream_t)st_;
+    ORDER_LM(c, st);
+    const size_t M = (size_t)c->last_B * c->last_T;
+    const void* src; size_t cols;
+    switch (which) {
+        case 0: src = c->h; cols = c->d.hidden; break;
+        case 1: src = c->xn; cols = c->d.hidden; break;
+        case 2: src = c->q_rot; cols = (size_t)c->d.heads * c->d.head_dim; break;
+        case 3: src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
+        case 4:
+            if (c->act_kb_rows) {                                  // the mid-M path leaves the activation k-blocked
+                HIPCHK(c, aha_kblocked_to_rows(c->act, c->act_kb_rows, c->d.inter, (bf16*)out, c->d.inter, st));
+                return 0;
+            }
+            src = c->act; cols = c->d.inter; break;
+        default: return fail(c, AHA_E_INVAL, "unknown tap");
+    }
+    HIPCHK(c, hipMemcpyAsync(out, src, M * cols * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int aha_lm_last_step_work(aha_ctx* c, double* wb, double* kvb, double* fl) {
+    if (!c) return AHA_E_INVAL;
+    if (wb) *wb = c->last_weight_bytes;
+    if (kvb) *kvb = c->last_kv_bytes;
+    if (fl) *fl = c->last_flops;
+    return 0;
+}
+
+extern "C" int aha_lm_last_gemm_time(aha_ctx* c, int kind, float* ms, int* launches, double* bytes) {
+    if (!c || kind < -1 || kind >= GK_COUNT) return AHA_E_INVAL;
+    float total = 0.f;
+    int n = 0;
+    double by = 0;
+    for (int k = 0; k < GK_COUNT; ++k) {
+        if (kind == -1 ? k >= GK_GEMMS : kind != k) continue;          // -1: the four GEMM kinds together
+        for (int i = 0; i < c->ev_used[k]; ++i) {
+            float t = 0.f;
+            HIPCHK(c, hipEventSynchronize(c->ev[k][i].second));
+            HIPCHK(c, hipEventElapsedTime(&t, c->ev[k][i].first, c->ev[k][i].second));
+            total += t;
+            ++n;
+        }
+        by += c->gk_bytes[k];
+    }
+    if (ms) *ms = total;
+    if (launches) *launches = n;
+    if (bytes) *bytes = by;
+    return 0;
+}
+
