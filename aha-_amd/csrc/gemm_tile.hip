@@ -625,6 +625,169 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 4) void gemm_tile_dma32_ker
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64x64 tile with SOFTWARE-PIPELINED k-steps (round 3) for the latency path: one to four frames (M = 576 .. 2304), where a
+// GEMM is 72-576 small tiles and every workgroup's k-loop is a serial chain.  gemm_tile_dma_kernel<2,2,2,2,3> spends
+// ~600 cycles per 64-deep k-tile on 8 MFMAs per wave (wait -> barrier -> fragment reads -> MFMAs, nothing overlapped): fc2's
+// K = 4096 alone is 22 us.  Here the k-step is split around ONE barrier like gemm_tile_p288s_kernel:
+//   TOP(s): MFMAs of k-half 0 (fragments read during MID(s-1)) | k-half 1 fragments of stage s by inline-asm ds_read_b128
+//           (issued behind the first MFMA, so that no compiler-inserted lgkmcnt wait can catch them) | DMA pieces 0,1 of s+3
+//   MID(s): lgkmcnt(0) -> vmcnt(6) -> s_barrier -> MFMAs of k-half 1 | k-half 0 fragments of stage s+1 | DMA pieces 2,3 of s+3
+// 4 stages of 16 KB (2 workgroups per CU), 4 waves as 2x2 with 32x32 wave tiles, four 1-KiB pieces per wave per stage.
+// Same k order per output element as every other variant: bit-identical.  K % 64 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tile_ps64_kernel(GemmTileArgs g) {
+    constexpr int BM = 64, BN = 64, STAGES = 4, ROWS = BM + BN, STAGE = ROWS * TBK, P = 4;
+    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
+    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = ceil_div(g.N, BN), tiles_m = ceil_div(g.M, BM);
+    const int nblk = tiles_n * tiles_m;
+    int bid = blockIdx.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * GROUP_M;
+    const int gmn = min(tiles_m - first_m, GROUP_M), inner = bid % per_group;
+    const int bm = first_m + inner % gmn, bn = inner / gmn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nk = g.K / TBK;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // DMA piece p = 8 rows of the stage image (rows [0,64) from A, [64,128) from W); wave w issues pieces w, w+4, w+8, w+12
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const bf16* src[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        src[i] = row < BM ? g.A + min(m0 + row, g.M - 1) * g.lda + ch * 8
+                          : g.W + min(n0 + row - BM, g.N - 1) * g.ldw + ch * 8;
+    }
+    auto dma_piece = [&](int i, int kt, int stage) {
+        const int k0 = min(kt, nk - 1) * TBK;                      // past the end: refill a dead stage (keeps the vmcnt counts fixed)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + k0), (lptr_t)(lds + stage * STAGE + (wave + 4 * i) * 512), 16, 0, 0);
+    };
+    // fragment addresses: row = (multiple of 16) + r16, so the swizzle key (row & 7) is (r16 & 7) for every fragment
+    const unsigned off0 = (unsigned)r16 * (TBK * 2) + ((q ^ (r16 & 7)) << 4), off1 = off0 ^ 64u;     // k-half 0 / 1: chunk bit 2
+    const char* lds_b = reinterpret_cast<const char*>(lds);
+    const unsigned lds_u32 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)dsm_raw;
+    bf16x8 a0[2], w0[2], a1[2], w1[2];
+    auto read_half0 = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a0[i] = *reinterpret_cast<const bf16x8*>(lds_b + stage * (STAGE * 2) + (wm * 32 + i * 16) * (TBK * 2) + off0);
+            w0[i] = *reinterpret_cast<const bf16x8*>(lds_b + stage * (STAGE * 2) + (BM + wn * 32 + i * 16) * (TBK * 2) + off0);
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+#pragma unroll
+        for (int i = 0; i < P; ++i) dma_piece(i, s, s);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_half0(0);
+    int st_cur = 0, st_new = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st_next = st_cur == STAGES - 1 ? 0 : st_cur + 1;
+        // ---- TOP
+        acc[0][0] = mfma16(w0[0], a0[0], acc[0][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned va = lds_u32 + st_cur * (STAGE * 2) + wm * (32 * TBK * 2) + off1;
+            const unsigned vw = lds_u32 + st_cur * (STAGE * 2) + (BM + wn * 32) * (TBK * 2) + off1;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(a1[0]) : "v"(va) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(a1[1]) : "v"(va) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(w1[0]) : "v"(vw) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(w1[1]) : "v"(vw) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][1] = mfma16(w0[1], a0[0], acc[0][1]);
+        dma_piece(0, kt + STAGES - 1, st_new);
+        acc[1][0] = mfma16(w0[0], a0[1], acc[1][0]);
+        dma_piece(1, kt + STAGES - 1, st_new);
+        acc[1][1] = mfma16(w0[1], a0[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MID
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P + 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma16(w1[0], a1[0], acc[0][0]);
+        read_half0(st_next);
+        acc[0][1] = mfma16(w1[1], a1[0], acc[0][1]);
+        dma_piece(2, kt + STAGES - 1, st_new);
+        acc[1][0] = mfma16(w1[0], a1[1], acc[1][0]);
+        dma_piece(3, kt + STAGES - 1, st_new);
+        acc[1][1] = mfma16(w1[1], a1[1], acc[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        st_cur = st_next;
+        st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
+
+    if (tile_epilogue_wide_ok(g)) {                                // uniform
+        __builtin_amdgcn_s_barrier();                              // every wave is done reading the stages: they become staging
+        tile_epilogue_lds<2, 2>(g, acc, lds + wave * (32 * (32 + 8)), m0 + wm * 32, n0 + wn * 32, lane);
+        return;
+    }
+    const bf16x4 z4 = {0, 0, 0, 0};
+    bf16x4 bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = min(n0 + wn * 32 + j * 16 + q * 4, g.N - 4);
+        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 32 + i * 16 + r16;
+        const int mc = min(m, g.M - 1);
+        bf16x4 rv[2], pv[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = min(n0 + wn * 32 + j * 16 + q * 4, g.N - 4);
+            rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
+            pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
+        }
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + q * 4;
+            if (n >= g.N) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = tile_act(acc[i][j][e] + bf2f(bv[j][e]), g.act);
+                if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
+                if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
+                o[e] = f2bf(x);
+            }
+            *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
+        }
+    }
+}
+
+static hipError_t launch_ps64(const GemmTileArgs* g, hipStream_t st) {
+    constexpr int lds_bytes = 4 * 128 * TBK * 2;                   // 64 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_ps64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nblk = ceil_div(g->N, 64) * ceil_div(g->M, 64);
+    hipLaunchKernelGGL(gemm_tile_ps64_kernel, dim3(nblk), dim3(256), lds_bytes, st, *g);
+    return hipGetLastError();
+}
+
 template <int WI, int WJ, int WAVES_M, int WAVES_N, int STAGES>
 static hipError_t launch_dma32(const GemmTileArgs* g, hipStream_t st) {
     constexpr int BM = WAVES_M * 16 * WI, BN = WAVES_N * 16 * WJ;
@@ -872,6 +1035,7 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
         case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
+        case 14: return launch_ps64(g, st);                      //  64x64, software-pipelined k-steps, 64 KB (2 per CU): the latency path
         case 12: return aha_gemm_tile_p288_ok(g) && g->wide_epi ? aha_gemm_tile_p288(g, st) : launch_dma32<4, 4, 4, 2, 3>(g, st);   // persistent 288x256 (gemm_tile_p.hip)
         default: return hipErrorInvalidValue;
     }
@@ -919,6 +1083,9 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
             if (g->K < 2048 && t288 > 400 && t288 <= 512 && nblk_l > 512) v = 11;
             else if (g->K < 2048 && nblk_l >= 400) v = 8;     // 32-deep stages, two workgroups per CU: +7-10 % on the K = 1024 GEMMs
             else v = ((util >= 0.6f || (g->K >= 2048 && util >= 0.5f)) && (g->N > 1024 || g->K > 1024)) ? 2 : 5;
+            // latency path (one or two frames): the narrow GEMMs (out-proj, fc2, patch embedding: N <= 1024) are <= 288 64x64 tiles,
+            // one per CU, each a serial k-chain - the software-pipelined 64x64 kernel (M = 576: fc2 21.9 -> 16.4 us, out-proj 8.1 -> 6.6)
+            if (v == 5 && g->N <= 1024 && g->M <= 1536) v = 14;
         }
         return launch_dma_variant(v, g, st);
     }
