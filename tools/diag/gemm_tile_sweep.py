@@ -12,6 +12,8 @@ def dev_gemm(A, W, C, M, N, K, v, st):
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
 Ms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [576, 1152, 2304, 4608, 18432]
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
+if len(sys.argv) > 3 and sys.argv[3] == "so400m":
+    shapes = [(3456, 1152), (1152, 1152), (4304, 1152), (1152, 4352)]
 NW = 24
 st = torch.cuda.current_stream().cuda_stream
 for M in Ms:

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Race screen of the hand-synchronised round-3 kernels (cdna_hip_programming.md: a sync-structure edit makes a new template - screen
+it over many runs at several sizes): every launch's output is compared bit for bit with the result of an independently synchronised
+kernel of the same arithmetic.  python tools/diag/race_screen.py [rounds]"""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import aha_amd
+from aha_amd.config import preset
+from aha_amd.synth import make_weights
+from aha_amd.runtime import Runtime
+lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", "libaha_amd.so"))
+lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+st = torch.cuda.current_stream().cuda_stream
+bad = total = 0
+g = torch.Generator(device="cuda").manual_seed(1)
+# persistent 288x256 (pipelined = variant 12 with the default switch, plain loop with tile_p288s = 0) and the pipelined 64x64 (14)
+for M, N, K in [(18432, 3072, 1024), (18432, 1024, 4096), (9792, 4096, 1024), (18432 + 100, 1152, 640), (4608, 3584, 3584), (73728, 1024, 1024),
+                (576, 1024, 4096), (576, 3072, 1024), (1731, 1024, 1024)]:
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty_like(ref)
+    assert lib.aha_dev_gemm_tile(A.data_ptr(), W.data_ptr(), ref.data_ptr(), M, N, K, 0 if M < 4000 else 8, st) == 0
+    for variant, piped in ((12, 1), (12, 0), (14, 1)):
+        if variant == 14 and M > 2304: continue
+        lib.aha_gemm_tile_p288_set_pipelined(piped)
+        n_bad = 0
+        for r in range(rounds):
+            out.fill_(7.0)
+            assert lib.aha_dev_gemm_tile(A.data_ptr(), W.data_ptr(), out.data_ptr(), M, N, K, variant, st) == 0
+            n_bad += int(not torch.equal(out, ref))
+        total += rounds; bad += n_bad
+        print(f"gemm M={M:6d} N={N:5d} K={K:5d} variant {variant}{'s' if piped and variant == 12 else ''}: {n_bad} of {rounds} launches differ", flush=True)
+lib.aha_gemm_tile_p288_set_pipelined(1)
+# head-resident dense attention against the restaging kernel
+cfg = preset("tiny")
+rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16), max_step_tokens=64, max_vit_frames=1, max_positions=256)
+for n, T in ((32, 576), (9, 500), (64, 576)):
+    qkv = torch.randn(n, T, 3 * 1024, generator=g, device="cuda").bfloat16()
+    rt.set_tuning("attn_head", 0); ref = rt.vit_attention(qkv, 16, 64).clone()
+    rt.set_tuning("attn_head", 2)
+    n_bad = sum(int(not torch.equal(rt.vit_attention(qkv, 16, 64), ref)) for _ in range(rounds))
+    total += rounds; bad += n_bad
+    print(f"attn_head64 n={n} T={T}: {n_bad} of {rounds} launches differ", flush=True)
+print(f"RACE SCREEN: {bad} differing launches of {total}")
+sys.exit(1 if bad else 0)
