@@ -25,6 +25,13 @@ template <int D> struct AttnCfg {
                                                // touches in one transposed read start 8 banks apart (conflict-free)
     static constexpr int DT = D / 16;          // d-tiles of the output
     static constexpr int KSQ = D / 32;         // k-steps of the QK^T product
+    // LDS slot of 16-B chunk ch of key row `row`: the 16 rows one ds_read_b128 quarter-wave reads must land on 16 different
+    // 16-byte bank groups.  Power-of-two rows (128 / 256 B) fold the row into the chunk; 192-byte rows (D = 96) already step
+    // 64 B per row mod 256, so only rows 4 apart collide and the XOR rotates within a group of four chunks.
+    static __device__ __forceinline__ int kslot(int row, int ch) {
+        if constexpr ((CPR & (CPR - 1)) == 0) return ch ^ (row & (CPR - 1));
+        else return ch ^ ((row >> 2) & 3);
+    }
 };
 
 template <int D, bool LM>
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
             const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
             const bool pad = ch * 8 >= a.hd;
             const bf16x8 kv = pad ? z8 : kreg[i], vv = pad ? z8 : vreg[i];
-            *reinterpret_cast<bf16x8*>(&Ks[row * D + ((ch ^ (row & (C::CPR - 1))) << 3)]) = kv;
+            *reinterpret_cast<bf16x8*>(&Ks[row * D + (C::kslot(row, ch) << 3)]) = kv;
             *reinterpret_cast<bf16x8*>(&Vs[row * C::VST + ch * 8]) = vv;
         }
         __syncthreads();
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
                 const int row = kt * 16 + r16;
 #pragma unroll
                 for (int ks = 0; ks < C::KSQ; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (row & (C::CPR - 1))) << 3)]);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (C::kslot(row, ks * 4 + q4) << 3)]);
                     s[kt] = mfma16(kf, qf[tt][ks], s[kt]);
                 }
             }
@@ -963,6 +970,8 @@ static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of t
 extern "C" void aha_attention_set_dense_tpw(int v) { g_dense_tpw = v; }
 static int g_attn_head = 1;      // tuning "attn_head": whole-head-in-LDS dense attention (0 off, 1 auto, 2 always when eligible)
 extern "C" void aha_attention_set_head_kernel(int v) { g_attn_head = v; }
+static int g_attn_d96 = 1;       // tuning "attn_d96": 96-wide dense template for head dims 65..96 (so400m's 72): 0 = pad to 128 as round 2
+extern "C" void aha_attention_set_d96(int v) { g_attn_d96 = v; }
 static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-sized steps (> 64 rows per KV head, head_dim 128): 0 never, 1 auto, 2 always
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
@@ -1035,8 +1044,8 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
 }
 
 // sd_dev: DEVICE pointer to the step descriptor (LM mode), or nullptr: dense (ViT) mode, requires n_splits == 1.
-// head_dim: any multiple of 8 up to 128; it runs the 64- or 128-wide template with the surplus
-// channels zero-padded on chip (so400m: 72 -> 128).
+// head_dim: any multiple of 8 up to 128; it runs the 64-, 96- (dense only) or 128-wide template with the surplus
+// channels zero-padded on chip (so400m: 72 -> 96).
 extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
     if (!sd && a_->n_splits != 1) return hipErrorInvalidValue;
     if (a_->n_splits < 1 || a_->n_splits > 16) return hipErrorInvalidValue;      // the combine kernels hold one value per split in registers
@@ -1044,5 +1053,13 @@ extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int 
     AttnArgs a = *a_;
     a.hd = head_dim;
     if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
+    if (!sd && head_dim <= 96 && g_attn_d96) {
+        // dense heads of 65..96 channels (so400m: 72): 3 QK^T k-steps and 6 output tiles instead of the 128-wide template's 4 and 8.
+        // The padded channels are exact zeros in both templates, so a row's bits do not depend on which one ran.
+        // Measured at 32 frames x 729 keys x 16 heads of 72: 279 -> 243 us per layer; two query tiles per wave: 306 us (worse).
+        const int RT = ceil_div(a.G * a.T, 16);
+        hipLaunchKernelGGL((attn_dense_kernel<96, 1>), dim3(1, a.Hkv * ceil_div(RT, 4), B), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     return launch_attn<128>(a, sd, B, st);
 }

@@ -5,7 +5,7 @@ the reference runs, and every encoder layer teacher-forced from the bf16 oracle'
 
   attention (SiglipAttention core, models via video_head_live_llava_qwen.py:113-115): <= 1 ulp + the P->bf16 rounding allowance
       2^-8 * sum_j p_j |v_jd|, at (576 keys, d 64: the head-resident kernel AND the restaging kernel, bit-identical to each
-      other), (729 keys, d 72: the zero-padded 128-wide template), (500 keys: ragged tail block); probe rows that put all
+      other), (729 keys, d 72: the zero-padded 96-wide template, checked bit for bit against the 128-wide one), (500 keys: ragged tail block); probe rows that put all
       their weight on ONE key at the first / last / 64-key block edges must return that key's V.
   LayerNorm: <= 0.5 ulp + fp32 noise of an fp32-statistics evaluation (asserted <= 1 ulp, >= 99 % bit-equal to the rounded exact value)
   preprocess + patch unfold: EXACT (integer pixels through fixed fp32 constants)
@@ -125,6 +125,14 @@ def test_dense_attention_flat_bound(vit_l, case):
         rt.set_tuning("attn_head", 1)
     if D == 64:
         assert torch.equal(outs[0], outs[2]), "head-resident and restaging dense attention kernels must agree bit for bit"
+    else:
+        # 72 channels run the 96-wide template; tuning attn_d96 = 0 pads them to the 128-wide one (round 2): same bits
+        try:
+            rt.set_tuning("attn_d96", 0)
+            wide = rt.vit_attention(qkv, H, D).view(n, T, H, D)
+        finally:
+            rt.set_tuning("attn_d96", 1)
+        assert torch.equal(outs[1], wide), "the 96- and 128-wide dense attention templates must agree bit for bit"
 
 
 def test_dense_attention_kernel_choice_does_not_depend_on_the_batch(vit_l):
