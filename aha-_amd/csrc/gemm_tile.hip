@@ -1001,7 +1001,7 @@ static hipError_t launch_256(const GemmTileArgs* g, hipStream_t st) {
 // tuning "tile_dma": 0 disables the LDS-DMA family, 1 auto, >= 2 forces variant id (tests, sweeps) whenever K allows
 static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
-static int g_tile_p288 = 1;      // tuning "tile_p288": persistent 288x256 kernel where its decomposition fits (0: round-2 variants only)
+static int g_tile_p288 = 1;      // tuning "tile_p288": persistent 288x256 kernel where its decomposition fits (0: round-2 variants only; n > 1: efficiency threshold n %)
 extern "C" void aha_gemm_tile_set_p288(int on) { g_tile_p288 = on; }
 static int g_tile_epi = 1;       // tuning "tile_epi": 1 = LDS-transposed wide epilogue (default), 0 = direct 8-byte stores
 extern "C" void aha_gemm_tile_set_epi(int on) { g_tile_epi = on; }
@@ -1069,8 +1069,8 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
             const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
             v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
         }
-        if (v == 1 && g_tile_p288 && g->wide_epi && aha_gemm_tile_p288_ok(g) && aha_gemm_tile_p288_efficiency(g, 256) >= 0.74f) {
-            // throughput shapes whose 288 x 256 decomposition keeps the chip busy (tile padding x round quantisation >= 0.74:
+        if (v == 1 && g_tile_p288 && g->wide_epi && aha_gemm_tile_p288_ok(g) && aha_gemm_tile_p288_efficiency(g, 256) >= (g_tile_p288 > 1 ? 0.01f * g_tile_p288 : 0.70f)) {
+            // throughput shapes whose 288 x 256 decomposition keeps the chip busy (tile padding x round quantisation >= 0.70:
             // every tower and projector GEMM from 8 frames of 576 patches up): the persistent kernel (gemm_tile_p.hip).
             // Tuning "tile_p288" = 0 keeps the round-2 selection below.
             v = 12;

@@ -8,14 +8,16 @@ import aha_amd
 from aha_amd.config import preset
 from aha_amd.synth import make_weights, make_frames
 from aha_amd.runtime import Runtime
-cfg = preset("bench")
+cfg = preset(sys.argv[2] if len(sys.argv) > 2 else "bench")
 w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
 batches = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [32, 128, 8]
 for nmax in batches:
     rt = Runtime(cfg, w, max_step_tokens=64, max_vit_frames=nmax)
     fr = make_frames(nmax, cfg.vision.image_size, seed=1).cuda()
     ref = None
-    for p288, head in ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1)):
+    combos = ((0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 1))
+    if len(sys.argv) > 3: combos = tuple((int(v), 1) for v in sys.argv[3].split(","))
+    for p288, head in combos:
         rt.set_tuning("tile_p288", p288); rt.set_tuning("attn_head", head)
         for _ in range(2): out = rt.visual_embed(fr)
         torch.cuda.synchronize(); t = time.perf_counter()
