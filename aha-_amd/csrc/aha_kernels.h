@@ -107,6 +107,9 @@ void aha_attention_set_dense_tpw(int v);
 void aha_attention_set_lm_kernel(int v);
 void aha_attention_set_head_kernel(int v);
 void aha_attention_set_d96(int v);
+void aha_attention_set_bg(int v);
+void aha_gemm_tile_set_bg(int on);
+void aha_gemm_tile_set_bg_cus(int n);
 extern "C" void aha_gemm_wl_set_balanced(int on);
 hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd_dev, int B, int head_dim, hipStream_t st);   // sd_dev: DEVICE pointer or null (dense)
 hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st);

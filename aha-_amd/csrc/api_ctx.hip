@@ -144,6 +144,8 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "attn_lm") aha_attention_set_lm_kernel(value);   // 1 (default): frame-sized LM steps use attn_lm_kernel (LDS-DMA, all row tiles per workgroup)
     else if (k == "attn_head") aha_attention_set_head_kernel(value);   // whole-head-in-LDS dense (ViT) attention: 0 off, 1 auto, 2 always when eligible
     else if (k == "attn_d96") aha_attention_set_d96(value);             // 96-wide dense attention template for head dims 65..96: 0 pads to 128
+    else if (k == "tower_bg") { aha_gemm_tile_set_bg(value); aha_attention_set_bg(value); }   // background tower: one four-wave workgroup per CU, room left for LM workgroups (bench.py --overlap)
+    else if (k == "bg_cus") aha_gemm_tile_set_bg_cus(value);      // workgroups of the background tower GEMM (default 256: one per CU)
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
     else if (k == "tile_p288s") aha_gemm_tile_p288_set_pipelined(value);   // 1 (default): software-pipelined fragment reads in the persistent tile kernel

@@ -299,16 +299,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDes
 // TPW = 1 is the default.
 // ---------------------------------------------------------------------------------------------
 template <int D, int TPW>
-__global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
+static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const int by, const int b, bf16* Ks, bf16* Vs) {
     using C = AttnCfg<D>;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q4 = lane >> 4, r16 = lane & 15;
-    const int b = blockIdx.z;
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4 * TPW);
-    const int hk = blockIdx.y / RG, rg = blockIdx.y % RG;
+    const int hk = by / RG, rg = by % RG;
     const int Lk = a.Lk, ldk = a.ldk;
     const bf16* kb = a.k + b * a.kv_bs + hk * a.hd;
     const bf16* vb = a.v + b * a.kv_bs + hk * a.hd;
@@ -475,6 +471,26 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
             bf16x4 ov = {f2bf(o[tt][dt][0] * inv), f2bf(o[tt][dt][1] * inv), f2bf(o[tt][dt][2] * inv), f2bf(o[tt][dt][3] * inv)};
             if (dt * 16 + 4 * q4 < a.hd) *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
         }
+    }
+}
+
+template <int D, int TPW>
+__global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
+    attn_dense_body<D, TPW>(a, blockIdx.y, blockIdx.z, Ks, Vs);
+}
+// Background tower (tuning "tower_bg", see gemm_tile_bg_kernel): the same body, PERSISTENT - at most one workgroup per CU (the
+// launch pads its LDS request so that two do not fit) walks the (KV head x row group, frame) items; identical arithmetic per row.
+template <int D>
+__global__ __launch_bounds__(256, D <= 64 ? 4 : 2) void attn_dense_bg_kernel(AttnArgs a, int ny, int items) {
+    using C = AttnCfg<D>;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+        attn_dense_body<D, 1>(a, it % ny, it / ny, Ks, Vs);
+        __syncthreads();                                             // every wave is done with this item's K/V image
     }
 }
 
@@ -972,6 +988,8 @@ static int g_attn_head = 1;      // tuning "attn_head": whole-head-in-LDS dense 
 extern "C" void aha_attention_set_head_kernel(int v) { g_attn_head = v; }
 static int g_attn_d96 = 1;       // tuning "attn_d96": 96-wide dense template for head dims 65..96 (so400m's 72): 0 = pad to 128 as round 2
 extern "C" void aha_attention_set_d96(int v) { g_attn_d96 = v; }
+static int g_attn_bg = 0;        // tuning "tower_bg": dense attention as ONE four-wave workgroup per CU (LDS padded to 88 KB), see gemm_tile.hip
+extern "C" void aha_attention_set_bg(int v) { g_attn_bg = v; }
 static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-sized steps (> 64 rows per KV head, head_dim 128): 0 never, 1 auto, 2 always
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
@@ -1011,6 +1029,19 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
         // packed fp32 ops and skipping idle rescales did not move it either (profiles/r02_vit_batch.txt): the per-block chain
         // barrier -> fragment reads -> MFMA -> softmax -> MFMA runs with little overlap at ~108 us.  Default: one tile per wave, the
         // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
+        if (g_attn_bg) {
+            // background tower: the restaging kernel's body, persistent, capped at one workgroup per CU by an unused dynamic LDS request
+            constexpr int PAD = 70 * 1024;
+            static bool bg_attr = false;
+            if (!bg_attr) {
+                hipError_t e = hipFuncSetAttribute((const void*)attn_dense_bg_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, PAD);
+                if (e != hipSuccess) return e;
+                bg_attr = true;
+            }
+            const int ny = a.Hkv * RG, items = ny * B;
+            hipLaunchKernelGGL((attn_dense_bg_kernel<D>), dim3(items < 256 ? items : 256), dim3(256), PAD, st, a, ny, items);
+            return hipGetLastError();
+        }
         if constexpr (D == 64) {
             // whole head LDS-resident (attn_head64_kernel): 64-wide heads whose K + V fit the CU's LDS and whose query rows fit
             // 12 waves x 3 tiles; needs enough (frame, head) pairs to give every CU a workgroup (single-frame latency stays

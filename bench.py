@@ -52,6 +52,9 @@ def parse():
                    help="encode batch k+1 on a second HIP stream while the LM scores batch k (round 3: measured 1.8 %% SLOWER than serial with "
                         "the persistent tower kernels, which hold every CU for a whole GEMM; default off)")
     p.add_argument("--no-overlap", action="store_true", help="(default now; kept for old command lines)")
+    p.add_argument("--tower-bg", type=int, default=0,
+                   help="with --overlap: 1 = encode on the background tower kernels (one four-wave workgroup per CU, LM workgroups fit "
+                        "beside them); measured zero-sum like every overlap here (profiles/r03_overlap_background_tower.txt)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
@@ -179,8 +182,10 @@ class Workload:
     """B streams x F frames per step on one GPU: batched vision encode on a second HIP stream (double-buffered embeddings,
     events both ways) while the LM scores the previous batch; every batch's encode and all of its LM steps are timed."""
 
-    def __init__(self, rt, cfg, dev, B, F, cache, window, sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream, gather=None):
+    def __init__(self, rt, cfg, dev, B, F, cache, window, sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream, gather=None,
+                 tower_bg=False):
         self.rt, self.B, self.F, self.tf, self.H = rt, B, F, cfg.frame_num_tokens, cfg.lm.hidden_size
+        self.tower_bg = bool(tower_bg) and vit_stream is not main_stream
         self.frames_all, self.main_stream, self.vit_stream, self.gather = frames_all, main_stream, vit_stream, gather
         self.streams = [rt.open_stream(cache, window, sink, capacity=cfg.lm.max_position_embeddings) for _ in range(B)]
         self.scores_host = torch.empty((F, B, 3), dtype=torch.float32).pin_memory()
@@ -202,7 +207,13 @@ class Workload:
     def encode(self, k):
         with torch.cuda.stream(self.vit_stream):
             self.vit_stream.wait_event(self.emb_free[k & 1])           # the LM is done with this slot
-            self.rt.visual_embed(self.frames_all, out=self.emb_buf[k & 1])
+            if self.tower_bg:
+                self.rt.set_tuning("tower_bg", 1)                      # kernel choice is made at enqueue time
+            try:
+                self.rt.visual_embed(self.frames_all, out=self.emb_buf[k & 1])
+            finally:
+                if self.tower_bg:
+                    self.rt.set_tuning("tower_bg", 0)
             self.emb_ready[k & 1].record(self.vit_stream)
 
     def run(self, n_steps):
@@ -353,8 +364,9 @@ def main():
     frames_all = torch.cat(frames, 0)                              # [B*F,3,S,S] stream-major
 
     # The vision tower is MFMA-bound, the LM steps are HBM-bound and they use disjoint workspaces, so with --overlap the tower
-    # of batch k+1 runs on a second HIP stream while the LM scores batch k.  Default: one stream (the persistent tower kernels
-    # occupy every CU for a whole GEMM, so the LM's short kernels only queue behind them: profiles/r03_attn_splitwave_negative.txt).
+    # of batch k+1 runs on a second HIP stream while the LM scores batch k.  Default: one stream.  Measured zero-sum in every form
+    # (persistent tower, background tower that leaves room for LM workgroups on every CU, priorities): a second active queue costs
+    # each of the LM step's ~200 launches ~2.6 us, more than the tower's 15 % share returns (profiles/r03_overlap_background_tower.txt).
     main_stream = torch.cuda.Stream(priority=-1) if a.lm_priority else torch.cuda.current_stream()   # LM chain: short kernels
     vit_stream = torch.cuda.Stream() if not a.no_overlap else main_stream
     if a.vit_cus > 0 and not a.no_overlap:
@@ -368,8 +380,9 @@ def main():
         loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
         return gather_scores(loc, n_streams_global)               # -> [F, B*world, 3] in global stream order
 
+    tower_bg = (not a.no_overlap) and a.tower_bg == 1
     wl = Workload(rt, cfg, dev, B, F, cache, a.window, a.sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream,
-                  gather if use_dist else None)
+                  gather if use_dist else None, tower_bg=tower_bg)
 
     def sync():
         if use_dist:

@@ -250,3 +250,20 @@ def test_every_encoder_layer_teacher_forced(which, request):
     assert torch.isfinite(emb.float()).all()
     e = _ulp_at_scale(tower, final)
     _note(f"{which} tower free-running ({len(taps)} layers)", e)
+
+
+def test_background_tower_kernels_give_the_same_embeddings(vit_l):
+    """tuning tower_bg (bench.py --overlap --tower-bg 1): 128x128 four-wave persistent tile GEMM + persistent restaging attention,
+    one workgroup per CU - same k order and the same attention body, so the embeddings must not move by a bit (1 and 5 frames:
+    ragged last tiles included); tower_bg = 2 is the same tile with one workgroup per tile."""
+    cfg, _, rt = vit_l
+    from aha_amd.synth import make_frames
+    for n in (1, 5):
+        fr = make_frames(n, cfg.vision.image_size, seed=11 + n).cuda()
+        ref = rt.visual_embed(fr).clone()
+        try:
+            for mode in (1, 2):
+                rt.set_tuning("tower_bg", mode)
+                assert torch.equal(rt.visual_embed(fr), ref), (n, mode)
+        finally:
+            rt.set_tuning("tower_bg", 0)
