@@ -46,10 +46,11 @@ def overlapped(lm_stream, vit_stream, bg, n_enc):
     torch.cuda.synchronize()
     return lm, e0.elapsed_time(e1) / n_enc
 hi, lo = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)
-for graph in (1, 0):
-    rt.set_tuning("use_graph", graph)
-    print(f"use_graph={graph}: LM step alone {lm_alone(hi):.3f} ms", flush=True)
-    for bg, cus in ((0, 256), (1, 256), (1, 128), (1, 64), (1, 16), (2, 256)):
+modes = [(1, 0), (0, 0)] if len(sys.argv) < 2 else [(1, int(v)) for v in sys.argv[1].split(",")]
+for graph, fuse in modes:
+    rt.set_tuning("use_graph", graph); rt.set_tuning("fuse_mlp", fuse % 10); rt.set_tuning("wpb_gateup", 8 if fuse else 5)
+    print(f"use_graph={graph} fuse_mlp={fuse}: LM step alone {lm_alone(hi):.3f} ms", flush=True)
+    for bg, cus in ((0, 256), (1, 256), (1, 64), (1, 16)):
         rt.set_tuning("bg_cus", cus)
         n_enc = 6 if bg == 0 else 4
         lm, enc = overlapped(hi, lo, bg, n_enc)
