@@ -261,13 +261,16 @@ class Runtime:
         return out
 
     def lm_step(self, streams: Sequence[Stream], embeds: torch.Tensor, *, want_raw: bool = False,
-                want_hidden: bool = False):
-        """embeds bf16 [B,T,H] -> scores fp32 [B,3] (+ raw head logits [B,4], last hidden [B,H])."""
+                want_hidden: bool = False, out: Optional[torch.Tensor] = None):
+        """embeds bf16 [B,T,H] -> scores fp32 [B,3] (+ raw head logits [B,4], last hidden [B,H]).  `out`: a contiguous fp32 [B,3]
+        device tensor the scores are written into (a row of a per-step score table: no allocation, no copy kernel)."""
         assert embeds.is_cuda and embeds.dtype == torch.bfloat16 and embeds.dim() == 3
         embeds = embeds.contiguous()
         B, T, _ = embeds.shape
         assert B == len(streams)
-        scores = torch.empty((B, 3), dtype=torch.float32, device=self.device)
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float32 and out.shape == (B, 3) and out.is_contiguous()
+        scores = out if out is not None else torch.empty((B, 3), dtype=torch.float32, device=self.device)
         raw = torch.empty((B, 4), dtype=torch.float32, device=self.device) if want_raw else None
         hid = torch.empty((B, self.hidden_size), dtype=torch.bfloat16, device=self.device) if want_hidden else None
         arr = (C.c_void_p * B)(*[s.handle for s in streams])

@@ -226,7 +226,7 @@ class Workload:
                 self.main_stream.wait_event(self.emb_ready[k & 1])
                 emb = self.emb_buf[k & 1].view(B, F, tf, H)
                 for i in range(F):
-                    self.scores_dev[i] = self.rt.lm_step(self.streams, emb[:, i].contiguous())
+                    self.rt.lm_step(self.streams, emb[:, i].contiguous(), out=self.scores_dev[i])
                 self.emb_free[k & 1].record(self.main_stream)
                 if self.gather is not None:
                     self.last_global = self.gather(self.scores_dev)    # one collective per step on the [F, B, 3] score rows
@@ -413,8 +413,6 @@ def main():
         dist_info = {"allgather_us": ag_us, "ranks_seen": ranks_seen(), "backend": "RCCL (torch.distributed nccl)" if a.backend == "nccl" else "gloo",
                      "rows_per_rank": F * B, "bytes_per_rank": F * B * 12}
         assert dist_info["ranks_seen"] == a.gpus
-        if a.backend == "nccl" and not a.no_abi_allgather:       # the C ABI's own RCCL communicator, by default at every world size
-            dist_info["c_abi_allgather"] = abi_allgather_check(dist, rt, wl.scores_dev, rank, world, local)
     assert torch.isfinite(wl.scores_host).all()
 
     # Dominant kernel: the gate/up weight-streaming GEMM (fused SwiGLU), timed with HIP events on its launch stream around each of
@@ -449,6 +447,7 @@ def main():
         kinds[name] = {"ms": round(ms, 4), "launches": n, "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
     rt.set_tuning("time_gemm", 0)
 
+    scores_last = wl.scores_dev                                    # for the C-ABI all-gather check at the very end
     static_batched = sink_datum = eight_datum = None
     if secondary:
         static_batched = static_batching_datum(rt, wl, frames_all, F, tf, H, a.steps, sync)
@@ -466,10 +465,8 @@ def main():
         ref_datum = ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, sync)
     if rt is not None:
         rt.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()                               # nothing below talks to another rank
 
+    out = None
     if rank == 0:
         total_frames = F * B * world * a.steps
         rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,", "static_1stream")
@@ -496,7 +493,41 @@ def main():
                                                a.sink, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+
+    if use_dist:
+        # Last, and under a watchdog: the C ABI's own RCCL communicator (a diagnostic that has never run with more than one rank on
+        # hardware) and the final barrier.  If either stalls, rank 0 still prints the complete line and every rank leaves.
+        def give_up(what):
+            if rank == 0:
+                out["distributed"]["c_abi_allgather"] = out["distributed"].get("c_abi_allgather") or {"ok": None, "error": f"{what}: no answer within the watchdog; skipped"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        if a.backend == "nccl" and not a.no_abi_allgather:         # by default at every world size
+            res = guarded(lambda: abi_allgather_check(dist, None, scores_last, rank, world, local), 300.0, lambda: give_up("C-ABI all-gather check"))
+            if rank == 0:
+                out["distributed"]["c_abi_allgather"] = res
+
+        def leave():
+            dist.barrier()
+            dist.destroy_process_group()                           # nothing below talks to another rank
+        guarded(leave, 120.0, lambda: give_up("final barrier"))
+    if rank == 0:
         print(json.dumps(out))
+
+
+def guarded(fn, timeout_s, on_timeout):
+    """fn() with a watchdog thread: on_timeout() runs (and is expected to end the process) if fn has not returned in time."""
+    import threading
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(timeout_s):
+            on_timeout()
+    threading.Thread(target=watch, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
 
 
 def ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, sync):
@@ -555,7 +586,7 @@ def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
         # timeout), so a rank that cannot go on makes all ranks skip the diagnostic instead of stalling them.
         store = dist.distributed_c10d._get_default_store()
 
-        def agree(tag, ok_here, timeout_s=60.0):
+        def agree(tag, ok_here, timeout_s=240.0):     # rank 0 may still be timing the CPU baseline
             store.set(f"aha_abi_{tag}_{rank}", "1" if ok_here else "0")
             t_end = time.time() + timeout_s
             for r in range(world):
