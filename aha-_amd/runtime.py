@@ -300,9 +300,13 @@ class Runtime:
         self._chk(self.lib.aha_lm_logits_last(self.ctx, lg.data_ptr() if lg is not None else None, am.data_ptr(), _cur_stream()))
         return lg, am
 
-    def logits_all(self, B: int, T: int) -> torch.Tensor:
-        """lm_head over every position of the last step: fp32 [B,T,V] (video_head_live_llava_qwen.py:175)."""
-        lg = torch.empty((B * T, self.cfg.lm.vocab_size), dtype=torch.float32, device=self.device)
+    def logits_all(self, B: int, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """lm_head over every position of the last step: fp32 [B,T,V] (video_head_live_llava_qwen.py:175).  `out`: a contiguous fp32
+        device tensor of B*T*V elements to write into."""
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * T * self.cfg.lm.vocab_size
+        lg = out.view(B * T, self.cfg.lm.vocab_size) if out is not None else \
+            torch.empty((B * T, self.cfg.lm.vocab_size), dtype=torch.float32, device=self.device)
         self._chk(self.lib.aha_lm_logits_all(self.ctx, lg.data_ptr(), _cur_stream()))
         return lg.view(B, T, -1)
 

@@ -345,7 +345,7 @@ def main():
     n_sys, n_query = 35, 20
     secondary = (not a.no_secondary) and world == 1 and B == 1 and a.cache == "static" and a.preset == "bench"
     B2 = 8                                                        # configs[3]: 64 streams over 8 GPUs
-    w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=True)
+    w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=not secondary)   # lm_head only for the all-position-logits datum
     # vision batches: 32 frames for the headline stream (the reference pre-encodes 32 at a time, test/inference.py:181); the
     # 8-stream datum encodes its 256 frames per step in batches of 128 (better tile quantisation of the tower's N = 1024 GEMMs:
     # 18.2 vs 19.3 ms per 32 frames; a frame's embedding does not depend on the batch it is encoded in - bit-exact, tested)
@@ -448,8 +448,9 @@ def main():
     rt.set_tuning("time_gemm", 0)
 
     scores_last = wl.scores_dev                                    # for the C-ABI all-gather check at the very end
-    static_batched = sink_datum = eight_datum = None
+    static_batched = sink_datum = eight_datum = logits_datum = None
     if secondary:
+        logits_datum = all_position_logits_datum(rt, wl, frames_all, F, tf, H, cfg.lm.vocab_size, dt / a.steps * 1e3, sync)
         static_batched = static_batching_datum(rt, wl, frames_all, F, tf, H, a.steps, sync)
         wl.close()
         sink_datum = sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_stream, vit_stream, sync)
@@ -482,6 +483,7 @@ def main():
             "p50_frame_latency_ms": lat[len(lat) // 2],
             "roofline": rf,
             "distributed": dist_info,
+            "with_all_position_logits": logits_datum,
             "static_cache_batched_frames": static_batched,
             "sink_w2048": sink_datum,
             "eight_stream_sink": eight_datum,
@@ -631,6 +633,33 @@ def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
         return {"ok": bool(ok), "allgather_us": us, "ranks": world}
     except Exception as e:                                       # a diagnostic must not take the measurement down
         return {"ok": False, "error": repr(e)}
+
+
+def all_position_logits_datum(rt, wl, frames_all, F, tf, H, V, headline_ms, sync):
+    """secondary (NOT `value`): the reference's forward runs lm_head over EVERY position of every frame step (logits fp32 [1,T,V],
+    video_head_live_llava_qwen.py:175) and then uses none of it on a frame step; SURVEY.md 8(d) leaves lm_head out of the algorithmic
+    work and the headline loop does not compute it.  This datum does, so that the cost of the reference's literal per-frame work is
+    on record: the headline step + aha_lm_logits_all after every LM step (1.09 GB of lm_head weights and 21.9 MB of fp32 logits per frame)."""
+    logits = torch.empty((tf, V), dtype=torch.float32, device=frames_all.device)
+    streams, scores_dev, scores_host = wl.streams, wl.scores_dev, wl.scores_host
+
+    def step():
+        emb = rt.visual_embed(frames_all).view(F, tf, H)
+        for i in range(F):
+            rt.lm_step(streams, emb[i:i + 1], out=scores_dev[i])
+            rt.logits_all(1, tf, out=logits)
+        scores_host.copy_(scores_dev, non_blocking=True)
+    step()
+    sync()
+    assert torch.isfinite(logits).all()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    return {"workload": "the headline step + lm_head over all T positions after every frame's LM step (what the reference's forward computes)",
+            "frames_per_s": F / dt * 1e3, "ms_per_step": dt, "lm_head_ms_per_frame": (dt - headline_ms) / F}
 
 
 def static_batching_datum(rt, wl, frames_all, F, tf, H, steps, sync):
