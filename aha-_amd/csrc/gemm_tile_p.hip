@@ -23,6 +23,9 @@
 // (tests/test_gpu_parity.py::test_tiled_gemm_variants_are_bit_identical).
 #include "aha_kernels.h"
 #include "tile_act.h"
+#ifdef AHA_CLOCK_STAMP
+__device__ unsigned long long aha_clock_stamps[4 * 256];   // written by the diagnostic build only; no other code reads it
+#endif
 
 namespace {
 constexpr int PBM = 288, PBN = 256, PBK = 32, PSTAGES = 4;
@@ -51,6 +54,17 @@ template <int ACT, bool RES, bool ROWADD>
 static __device__ __forceinline__ void p288_epilogue(const GemmTileArgs& g, f32x4 (&acc)[PWI][PWJ], bf16* stg, const bf16* bias_lds, const int mw,
                                                      const int nw, const int lane) {
     const int q = lane >> 4, r16 = lane & 15;
+#ifdef AHA_ABL_NOEPI
+    {   // ablation build only (tools/micro/tile_clock.hip): no epilogue at all - one store keeps the accumulators live
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < PWI; ++i)
+#pragma unroll
+            for (int j = 0; j < PWJ; ++j) { s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (s == 12345.678f) g.C[lane] = f2bf(s);
+        return;
+    }
+#endif
     const int act = ACT < 0 ? g.act : ACT;
     const bool res = ACT < 0 ? g.residual != nullptr : RES, radd = ACT < 0 ? g.rowadd != nullptr : ROWADD;
     const bf16x4 z4 = {0, 0, 0, 0};
@@ -85,7 +99,11 @@ static __device__ __forceinline__ void p288_epilogue(const GemmTileArgs& g, f32x
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = f2bf(rbf(bf2f(v[e]) + bf2f(pv[e])));
             }
+#ifdef AHA_ABL_NOSTORE
+            if (m < g.M && n < g.N && v[0] == (bf16)12345.0f) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;   // ablation build only
+#else
             if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;
+#endif
         }
     }
 }
@@ -281,6 +299,10 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
     const int nk = g.K / PBK;
     const int my_tiles = bid < T ? (T - bid + G - 1) / G : 0;
     if (my_tiles == 0) return;
+#ifdef AHA_CLOCK_STAMP
+    // diagnostic build only (tools/micro/tile_clock.hip): shader-clock and 100 MHz reference stamps around the workgroup's whole tile stream
+    if (tid == 0) { aha_clock_stamps[4 * bid + 0] = __builtin_amdgcn_s_memtime(); aha_clock_stamps[4 * bid + 1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     const int total = my_tiles * nk;
     const int full_rounds = T / G;
     // j-th tile of this workgroup -> position in the locality-ordered sequence.  In a full round the workgroups of one XCD
@@ -488,6 +510,9 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
         p288_tile_coords(seq_of(c_j), tiles_m, tiles_n, &bm, &bn);
         ++c_j;
         const int mw = bm * PBM + wm * (16 * PWI), nw = bn * PBN + wn * (16 * PWJ);
+        // (Measured and dropped: issuing the next k-step's five pieces here, in front of the tile's stores - the stage they refill is
+        // already free - so that data issued behind the stores is first needed four k-steps later instead of three: QKV 112 -> 137 us,
+        // fc2 124 -> 137; same bits.  profiles/r03_tile_clock_ablation.txt.)
         const int combo = g.act * 4 + (g.residual ? 2 : 0) + (g.rowadd ? 1 : 0);
         switch (combo) {
             case ACT_NONE * 4 + 0: p288_epilogue<ACT_NONE, false, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
@@ -503,6 +528,9 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
         relax_n = (bm * PBM + PBM <= g.M && bn * PBN + PBN <= g.N) ? 19 : 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
+#ifdef AHA_CLOCK_STAMP
+    if (tid == 0) { aha_clock_stamps[4 * bid + 2] = __builtin_amdgcn_s_memtime(); aha_clock_stamps[4 * bid + 3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 static int g_p288_cus = 0;

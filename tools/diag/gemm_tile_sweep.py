@@ -3,7 +3,7 @@ the plain k-step loop, 13 = the same kernel with software-pipelined fragment rea
 Weights cycle over 24 distinct buffers (a tower's worth), so they stream from HBM as in the real encode."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", "libaha_amd.so"))
+lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", os.environ.get("AHA_SWEEP_LIB", "libaha_amd.so")))
 lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 _raw = lib.aha_dev_gemm_tile
 def dev_gemm(A, W, C, M, N, K, v, st):
