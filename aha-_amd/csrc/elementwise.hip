@@ -518,17 +518,20 @@ __global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, in
     *reinterpret_cast<bf16x8*>(out + rowi * Kp + kc * 8) = o;
 }
 
-// LayerNorm over the last dim, one wave per row (4 rows per block); D % 8 == 0, D <= 4096.
+// LayerNorm over the last dim, one wave per row (4 rows per block); D % 8 == 0, D <= 4096.  NC = 16-byte chunks per lane the
+// instantiation holds (ceil(D / 512) <= NC): the 8-chunk form needs 132 VGPRs (3 waves per SIMD, two loads in flight per wave
+// at D = 1024: 3.8 TB/s on the 32-frame tower); the 2- and 3-chunk forms run at full occupancy.  Same per-lane order: same bits.
+template <int NC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
                                                         const bf16* __restrict__ bias, bf16* __restrict__ out, int ldo,
                                                         int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nch = D >> 3;
-    bf16x8 v[8];
+    bf16x8 v[NC];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             v[i] = *reinterpret_cast<const bf16x8*>(x + (long)row * ldx + c * 8);
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
     const float mean = wave_sum(s) / (float)D;
     float vs = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
 #pragma unroll
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
     }
     const float rstd = rsqrtf(wave_sum(vs) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
             const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
@@ -816,7 +819,11 @@ hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* p
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
                          hipStream_t st) {
     if ((D & 7) || D > 4096) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, st, x, ldx, w, b, out, ldo, M, D, eps);
+    const int nc = ceil_div(D >> 3, 64);
+    const dim3 grid(ceil_div(M, 4)), blk(256);
+    if (nc <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
+    else if (nc <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
     return hipGetLastError();
 }
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st) {
