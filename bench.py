@@ -218,6 +218,7 @@ class Workload:
 
     def run(self, n_steps):
         B, F, tf, H = self.B, self.F, self.tf, self.H
+        pending = None
         with torch.cuda.stream(self.main_stream):
             self.encode(0)
             for k in range(n_steps):
@@ -229,8 +230,14 @@ class Workload:
                     self.rt.lm_step(self.streams, emb[:, i].contiguous(), out=self.scores_dev[i])
                 self.emb_free[k & 1].record(self.main_stream)
                 if self.gather is not None:
-                    self.last_global = self.gather(self.scores_dev)    # one collective per step on the [F, B, 3] score rows
+                    # one collective per step on the [F, B, 3] score rows, started here and waited for a step later: it runs
+                    # underneath the next step's LM launches; the last one is resolved before run() returns
+                    if pending is not None:
+                        self.last_global = pending.result()
+                    pending = self.gather(self.scores_dev)
                 self.scores_host.copy_(self.scores_dev, non_blocking=True)
+            if pending is not None:
+                self.last_global = pending.result()
 
     def last_emb(self, n_steps):
         return self.emb_buf[(n_steps - 1) & 1].view(self.B, self.F, self.tf, self.H)
@@ -310,7 +317,7 @@ def main():
 
     import aha_amd  # noqa: F401
     from aha_amd.config import preset
-    from aha_amd.sharding import gather_scores
+    from aha_amd.sharding import gather_scores, gather_scores_async
     from aha_amd.synth import make_frames, make_token_ids, make_weights
 
     B, F = a.streams, a.frames
@@ -378,7 +385,7 @@ def main():
 
     def gather(scores_dev):
         loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
-        return gather_scores(loc, n_streams_global)               # -> [F, B*world, 3] in global stream order
+        return gather_scores_async(loc, n_streams_global)         # handle; .result() -> [F, B*world, 3] in global stream order
 
     tower_bg = (not a.no_overlap) and a.tower_bg == 1
     wl = Workload(rt, cfg, dev, B, F, cache, a.window, a.sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream,
@@ -403,15 +410,16 @@ def main():
         dt = t.item()
         # the collective on its own: one all-gather of the [F, B, 3] rows per step (latency-bound: a few hundred bytes per rank)
         for _ in range(5):
-            gather(wl.scores_dev)
+            gather(wl.scores_dev).result()
         sync()
         t1 = time.perf_counter()
         for _ in range(50):
-            gather(wl.scores_dev)
+            gather(wl.scores_dev).result()
         torch.cuda.synchronize()
         ag_us = (time.perf_counter() - t1) / 50 * 1e6
         dist_info = {"allgather_us": ag_us, "ranks_seen": ranks_seen(), "backend": "RCCL (torch.distributed nccl)" if a.backend == "nccl" else "gloo",
-                     "rows_per_rank": F * B, "bytes_per_rank": F * B * 12}
+                     "rows_per_rank": F * B, "bytes_per_rank": F * B * 12,
+                     "overlap": "step k's all-gather is waited for after step k+1's LM launches are enqueued"}
         assert dist_info["ranks_seen"] == a.gpus
     assert torch.isfinite(wl.scores_host).all()
 

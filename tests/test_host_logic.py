@@ -178,6 +178,15 @@ def _rank_main(rank, world, port, n_streams, ret):
     local = torch.stack([torch.stack([torch.tensor([s + 0.1 * f, s + 0.2, -float(s)]) for s in mine]) for f in range(F)]) \
         if mine else torch.zeros((F, 0, 3))
     glob = gather_scores(local.float(), n_streams)
+    # two gathers in flight, resolved later and in the other order; the local rows are overwritten right after the start
+    from aha_amd.sharding import gather_scores_async
+    loc2 = local.float().clone()
+    h1 = gather_scores_async(loc2, n_streams)
+    loc2 += 100.0
+    h2 = gather_scores_async(loc2, n_streams)
+    loc2.zero_()
+    g2, g1 = h2.result(), h1.result()
+    assert torch.equal(g1, glob) and torch.equal(g2, glob + 100.0) and h1.result() is g1
     ret[rank] = glob.numpy().copy()
     dist.barrier()
     dist.destroy_process_group()
