@@ -37,7 +37,9 @@ def step_ms(sts, x, n=20):
     return (time.perf_counter() - t) / n * 1e3
 
 
-for B in (1, 4, 8):
+LENS = [int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (0, 192, 256, 320, 384, 512, 1088)
+BS = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 4, 8)
+for B in BS:
     sts = [rt.open_stream("default_sink", 2048, 32) for _ in range(B)]
     x = (torch.randn(B, tf, H, generator=g, device="cuda") * 0.05).bfloat16()
     for _ in range(60):
@@ -45,7 +47,7 @@ for B in (1, 4, 8):
     for mode in (1, 2):
         rt.set_tuning("attn_lm", mode)
         row = []
-        for sl in (0, 192, 256, 320, 384, 512, 1088):
+        for sl in LENS:
             rt.set_tuning("attn_split_len", sl)
             row.append(f"{sl}: {attn_us(sts, x):.1f}")
         print(f"B={B} attn_lm={mode}  us per layer by split_len  " + "  ".join(row), flush=True)
