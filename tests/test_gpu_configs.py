@@ -412,6 +412,19 @@ def test_all_position_logits_match_last_position_and_oracle():
     assert e.max().item() <= 0.5 + 1e-6
     want = OracleLM(cfg.lm, w, torch.bfloat16).step(x, GrowingPolicy(), want_logits=True)["logits"]
     assert (lg.cpu() - want).abs().max().item() <= 0.08
+    # caller-provided destinations (bench.py's score table and logits buffer): same values, written in place
+    st = rt.open_stream(None, capacity=64)
+    ref_scores = rt.lm_step([st], x.cuda()).clone()
+    ref_logits = rt.logits_all(1, 9).clone()
+    st.close()
+    st = rt.open_stream(None, capacity=64)
+    table = torch.full((3, 1, 3), -7.0, device="cuda")
+    buf = torch.empty((9, cfg.lm.vocab_size), dtype=torch.float32, device="cuda")
+    got = rt.lm_step([st], x.cuda(), out=table[1])
+    assert got.data_ptr() == table[1].data_ptr() and torch.equal(table[1], ref_scores)
+    assert (table[0] == -7.0).all() and (table[2] == -7.0).all()
+    assert torch.equal(rt.logits_all(1, 9, out=buf).view(9, -1), ref_logits.view(9, -1)) and torch.equal(buf, ref_logits.view(9, -1))
+    st.close()
     rt.close()
 
 
