@@ -185,6 +185,7 @@ extern "C" int aha_vit_layers_forward(aha_ctx* c, const void* x, int n, int laye
 extern "C" int aha_layernorm_forward(aha_ctx* c, const void* x, int ldx, const void* w, const void* b, void* out, int ldo, int rows, int cols,
                                      float eps, aha_hip_stream st_) {
     if (!c || !x || !w || !b || !out || rows <= 0 || cols <= 0 || (cols & 7) || cols > 4096) return AHA_E_INVAL;
+    if (ldx < cols || ldo < cols || (ldx & 7) || (ldo & 7)) return fail(c, AHA_E_RANGE, "row strides must be >= cols and multiples of 8 elements");
     HIPCHK(c, aha_layernorm((const bf16*)x, ldx, (const bf16*)w, (const bf16*)b, (bf16*)out, ldo, rows, cols, eps, (hipStream_t)st_));
     return 0;
 }
@@ -202,8 +203,11 @@ extern "C" int aha_vit_patchify_forward(aha_ctx* c, const uint8_t* frames, int n
 // align_corners=False) to out_grid; 1 / 2: avg / max pool with kernel = stride; 3: adaptive_avg_pool2d to out_grid.
 extern "C" int aha_pool_forward(aha_ctx* c, const void* in, int n, int grid, int out_grid, int C_, int stride, int mode, int frame_rows, void* out,
                                 aha_hip_stream st_) {
-    if (!c || !in || !out || n <= 0 || grid <= 0 || out_grid <= 0 || C_ <= 0 || (C_ & 3) || mode < 0 || mode > 3) return AHA_E_INVAL;
+    if (!c || !in || !out || n <= 0 || grid <= 0 || out_grid <= 0 || C_ <= 0 || (C_ & 7) || mode < 0 || mode > 3) return AHA_E_INVAL;   // 8-channel chunks
     if (frame_rows < grid * grid) return fail(c, AHA_E_RANGE, "frame_rows < grid^2");
+    if ((mode == 1 || mode == 2) && (stride < 1 || (long)out_grid * stride > grid))
+        return fail(c, AHA_E_RANGE, "avg / max pooling reads rows (oy*stride + dy): needs stride >= 1 and out_grid * stride <= grid");
+    if ((mode == 0 || mode == 3) && out_grid > grid) return fail(c, AHA_E_RANGE, "out_grid > grid");
     HIPCHK(c, aha_pool((const bf16*)in, (bf16*)out, n, grid, out_grid, C_, stride, mode, frame_rows, (hipStream_t)st_));
     return 0;
 }

@@ -1084,7 +1084,7 @@ extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int 
     AttnArgs a = *a_;
     a.hd = head_dim;
     if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
-    if (!sd && head_dim <= 96 && g_attn_d96) {
+    if (!sd && head_dim <= 96 && g_attn_d96 && !g_attn_bg) {       // tower_bg: the 128-wide template below has the background form (same bits)
         // dense heads of 65..96 channels (so400m: 72): 3 QK^T k-steps and 6 output tiles instead of the 128-wide template's 4 and 8.
         // The padded channels are exact zeros in both templates, so a row's bits do not depend on which one ran.
         // Measured at 32 frames x 729 keys x 16 heads of 72: 279 -> 243 us per layer; two query tiles per wave: 306 us (worse).

@@ -558,9 +558,11 @@ extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st) 
     return hipGetLastError();
 }
 
-// what the shape must satisfy (the caller falls back to the other tile kernels otherwise)
+// what the shape must satisfy (the caller falls back to the other tile kernels otherwise).  K >= 4 k-steps: the next tile's bias
+// line is issued by LDS-DMA right behind an epilogue and only the THIRD k-step's strict vmcnt wait guarantees it has landed
+// before the next epilogue reads bias_lds (the first two waits are relaxed by the epilogue's younger stores).
 extern "C" int aha_gemm_tile_p288_ok(const GemmTileArgs* g) {
-    return (g->K % PBK) == 0 && g->K >= PBK && !(g->N & 7) && !(g->ldc & 7) && (!g->residual || !(g->ldr & 7)) &&
+    return (g->K % PBK) == 0 && g->K >= 4 * PBK && !(g->N & 7) && !(g->ldc & 7) && (!g->residual || !(g->ldr & 7)) &&
            (!g->rowadd || !(g->ldra & 7)) && !(g->lda & 7) && !(g->ldw & 7);
 }
 // share of the chip's MFMA time the 288 x 256 decomposition of this shape uses: tile padding x round quantisation

@@ -58,10 +58,9 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
-    p.add_argument("--abi-allgather", action="store_true", help="(default now; kept for old command lines)")
-    p.add_argument("--no-abi-allgather", action="store_true",
-                   help="skip the C-ABI collective (aha_allgather_scores: RCCL communicator from a unique id, compared with torch.distributed's "
-                        "result and timed); by default it runs whenever torch.distributed is up, its set-up fenced by a store-based agreement")
+    p.add_argument("--abi-allgather", action="store_true", help="(ignored; the C-ABI collective is checked by tools/abi_allgather_check.py in its own process group)")
+    p.add_argument("--no-abi-allgather", action="store_true", help="(ignored; kept for old command lines)")
+    p.add_argument("--no-configs3", action="store_true", help="with more than one rank: skip the configs[3] datum (8 streams per GPU on SinkCache)")
     p.add_argument("--no-ref-geometry", action="store_true", help="skip the secondary datum on the reference-faithful geometry (so400m/14@384, Tf=49)")
     p.add_argument("--dry-run-collective", action="store_true",
                    help="launcher / rendezvous / all-gather plumbing only, on synthetic score rows: no GPU, no hot path, value = null")
@@ -350,14 +349,18 @@ def main():
     tf, H = cfg.frame_num_tokens, cfg.lm.hidden_size
     cache = None if a.cache == "none" else a.cache
     n_sys, n_query = 35, 20
-    secondary = (not a.no_secondary) and world == 1 and B == 1 and a.cache == "static" and a.preset == "bench"
+    base_cfg = B == 1 and a.cache == "static" and a.preset == "bench"
+    secondary = (not a.no_secondary) and world == 1 and base_cfg
+    # more than one rank: the one multi-GPU configuration BASELINE.json names is configs[3] (8 streams per GPU, 64 over the node) -
+    # measured on every rank after the headline region, same barrier + max-over-ranks timing, the score rows all-gathered with RCCL
+    configs3 = (not a.no_secondary) and (not a.no_configs3) and world > 1 and base_cfg
     B2 = 8                                                        # configs[3]: 64 streams over 8 GPUs
     w = make_weights(cfg, device=dev, dtype=torch.bfloat16, skip_lm_head=not secondary)   # lm_head only for the all-position-logits datum
     # vision batches: 32 frames for the headline stream (the reference pre-encodes 32 at a time, test/inference.py:181); the
     # 8-stream datum encodes its 256 frames per step in batches of 128 (better tile quantisation of the tower's N = 1024 GEMMs:
     # 18.2 vs 19.3 ms per 32 frames; a frame's embedding does not depend on the batch it is encoded in - bit-exact, tested)
-    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max((B2 if secondary else B) * (tf + n_sys), 320),
-                 max_vit_frames=128 if secondary else 32, max_positions=cfg.lm.max_position_embeddings)
+    rt = Runtime(cfg, w, device=str(dev), max_step_tokens=max((B2 if (secondary or configs3) else B) * (tf + n_sys), 320),
+                 max_vit_frames=128 if (secondary or configs3) else 32, max_positions=cfg.lm.max_position_embeddings)
     if a.tile_dma >= 0:
         rt.set_tuning("tile_dma", a.tile_dma)
     want_cpu = (not a.no_cpu_baseline) and rank == 0             # rank 0 only, at every world size (timed after the ranks have parted)
@@ -445,6 +448,26 @@ def main():
             lat.append(e0.elapsed_time(e1))
     lat.sort()
 
+    # the two stages of the step on their own, HIP events on the launch stream (same process, right after the timed region):
+    # F LM steps as the timed loop issues them (graph replay), and one batched vision encode of the step's frames
+    def ev_ms(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    emb_v = emb_last.view(B, F, tf, H)
+
+    def lm_pass():
+        for i in range(F):
+            rt.lm_step(wl.streams, emb_v[:, i].contiguous(), out=wl.scores_dev[i])
+    lm_ms_per_step = ev_ms(lm_pass, 2) / F
+    vit_ms = ev_ms(lambda: rt.visual_embed(frames_all), 3)
+
     # per-kind GEMM breakdown of one LM step (diagnostic, outside the timed region)
     rt.set_tuning("time_gemm", 15)
     rt.lm_step(wl.streams, rt.visual_embed(one).view(B, tf, H))
@@ -455,13 +478,17 @@ def main():
         kinds[name] = {"ms": round(ms, 4), "launches": n, "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
     rt.set_tuning("time_gemm", 0)
 
-    scores_last = wl.scores_dev                                    # for the C-ABI all-gather check at the very end
-    static_batched = sink_datum = eight_datum = logits_datum = None
-    if secondary:
+    static_batched = sink_datum = eight_datum = logits_datum = growing_datum = None
+    if configs3:
+        wl.close()
+        eight_datum = eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync, rank=rank, world=world,
+                                         dist=dist, backend=a.backend)
+    elif secondary:
         logits_datum = all_position_logits_datum(rt, wl, frames_all, F, tf, H, cfg.lm.vocab_size, dt / a.steps * 1e3, sync)
         static_batched = static_batching_datum(rt, wl, frames_all, F, tf, H, a.steps, sync)
         wl.close()
         sink_datum = sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_stream, vit_stream, sync)
+        growing_datum = growing_600_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids)
         eight_datum = eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync)
     else:
         wl.close()
@@ -479,6 +506,26 @@ def main():
     if rank == 0:
         total_frames = F * B * world * a.steps
         rf = roofline_hbm("gemm_ws_kernel<MT,2,KC,SWIGLU> (gate/up projection + SwiGLU)", g_ms, g_n, g_bytes, "gemm_ws_kernel<3, 2,", "static_1stream")
+        # The dominant kernel is the BEST-placed part of the step; the fractions a reader should take away are the stages' and the
+        # whole step's (SURVEY.md 8d algorithmic work: LM = weights streamed once per step + K/V read; vision + projector = MFMA flops)
+        v, P = cfg.vision, cfg.vision.num_patches
+        vit_flops = B * F * (2.0 * P * (3 * v.patch_size ** 2 * v.hidden_size + v.num_hidden_layers * (4 * v.hidden_size ** 2 + 2 * v.hidden_size * v.intermediate_size))
+                             + 4.0 * P * P * v.hidden_size * v.num_hidden_layers
+                             + 2.0 * (4 * tf) * (v.hidden_size * H + H * H))          # projector on the 4*Tf rows bilinear pooling samples
+        vit_w_bytes = 2.0 * (3 * v.patch_size ** 2 * v.hidden_size + v.num_hidden_layers * (4 * v.hidden_size ** 2 + 2 * v.hidden_size * v.intermediate_size)
+                             + v.hidden_size * H + H * H)
+        lm_bytes = wb + kvb
+        step_ms = dt / a.steps * 1e3
+        rf["lm_step"] = {"bound": "hbm", "what": f"one whole LM step (28 layers + heads, B={B}, T={tf}): weights + K/V bytes / its time by HIP events",
+                         "achieved": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": lm_ms_per_step, "algorithmic_bytes": lm_bytes}
+        rf["vision"] = {"bound": "mfma", "what": f"tower + projector + pool of {B * F} frames: algorithmic flops / its time by HIP events",
+                        "achieved": vit_flops / (vit_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": vit_flops / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "ms": vit_ms, "algorithmic_flops": vit_flops}
+        rf["step"] = {"bound": "hbm", "what": "the whole timed step (vision batch + F LM steps): algorithmic HBM bytes / ms_per_step",
+                      "achieved": (F * lm_bytes + vit_w_bytes) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": (F * lm_bytes + vit_w_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "lm_share_of_step": F * lm_ms_per_step / step_ms, "vision_share_of_step": vit_ms / step_ms}
         out = {
             "metric": "frames/sec scored (whole node)", "value": total_frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -494,6 +541,7 @@ def main():
             "with_all_position_logits": logits_datum,
             "static_cache_batched_frames": static_batched,
             "sink_w2048": sink_datum,
+            "growing_600": growing_datum,
             "eight_stream_sink": eight_datum,
             "ref_so400m_384": ref_datum,
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
@@ -505,39 +553,13 @@ def main():
             out["cpu_baseline"] = None
 
     if use_dist:
-        # Last, and under a watchdog: the C ABI's own RCCL communicator (a diagnostic that has never run with more than one rank on
-        # hardware) and the final barrier.  If either stalls, rank 0 still prints the complete line and every rank leaves.
-        def give_up(what):
-            if rank == 0:
-                out["distributed"]["c_abi_allgather"] = out["distributed"].get("c_abi_allgather") or {"ok": None, "error": f"{what}: no answer within the watchdog; skipped"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        if a.backend == "nccl" and not a.no_abi_allgather:         # by default at every world size
-            res = guarded(lambda: abi_allgather_check(dist, None, scores_last, rank, world, local), 300.0, lambda: give_up("C-ABI all-gather check"))
-            if rank == 0:
-                out["distributed"]["c_abi_allgather"] = res
-
-        def leave():
-            dist.barrier()
-            dist.destroy_process_group()                           # nothing below talks to another rank
-        guarded(leave, 120.0, lambda: give_up("final barrier"))
+        # nothing below talks to another rank.  The C ABI's own collective (aha_allgather_scores) is not exercised here: it runs in
+        # its own process group (tools/abi_allgather_check.py; tests/test_gpu_configs.py launches it), where a stall is that program's
+        # non-zero exit and can never be reported as a successful bench.
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
-
-
-def guarded(fn, timeout_s, on_timeout):
-    """fn() with a watchdog thread: on_timeout() runs (and is expected to end the process) if fn has not returned in time."""
-    import threading
-    done = threading.Event()
-
-    def watch():
-        if not done.wait(timeout_s):
-            on_timeout()
-    threading.Thread(target=watch, daemon=True).start()
-    try:
-        return fn()
-    finally:
-        done.set()
 
 
 def ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, sync):
@@ -575,72 +597,6 @@ def ref_geometry_datum(dev, a, prefix_ids, query_ids, main_stream, vit_stream, s
     wl.close()
     rt.close()
     return out
-
-
-def abi_allgather_check(dist, rt, scores_dev, rank, world, local):
-    """aha_allgather_scores (RCCL communicator built from a unique id inside libaha_amd.so) against torch.distributed's result."""
-    import ctypes as C
-    from aha_amd import lib as L
-    lib = L.get()
-    try:
-        idb = (C.c_ubyte * L.COMM_ID_BYTES)()
-        box = [None]
-        if rank == 0 and lib.aha_comm_unique_id(idb, L.COMM_ID_BYTES) == 0:
-            box[0] = bytes(idb)
-        dist.broadcast_object_list(box, src=0)                    # every rank learns whether rank 0 has an id: all init or none does
-        if box[0] is None:
-            return {"ok": False, "error": "aha_comm_unique_id failed: " + lib.aha_comm_last_error().decode()}
-        idb = (C.c_ubyte * L.COMM_ID_BYTES).from_buffer_copy(box[0])
-        # ncclCommInitRank blocks until EVERY rank has joined, and a collective on a communicator that one rank failed to build
-        # never completes: both steps are fenced by an agreement through torch.distributed's key-value store (host side, with a
-        # timeout), so a rank that cannot go on makes all ranks skip the diagnostic instead of stalling them.
-        store = dist.distributed_c10d._get_default_store()
-
-        def agree(tag, ok_here, timeout_s=240.0):     # rank 0 may still be timing the CPU baseline
-            store.set(f"aha_abi_{tag}_{rank}", "1" if ok_here else "0")
-            t_end = time.time() + timeout_s
-            for r in range(world):
-                key = f"aha_abi_{tag}_{r}"
-                while True:
-                    try:
-                        if store.check([key]):
-                            break
-                    except Exception:
-                        pass
-                    if time.time() > t_end:
-                        return False
-                    time.sleep(0.01)
-                if store.get(key) != b"1":
-                    return False
-            return True
-
-        if not agree("ready", True):
-            return {"ok": False, "error": "not every rank reached the C-ABI communicator set-up: skipped on all ranks"}
-        comm = C.c_void_p()
-        rc = lib.aha_comm_init_rank(idb, L.COMM_ID_BYTES, world, rank, local, C.byref(comm))
-        if not agree("init", rc == 0):
-            if rc == 0:
-                lib.aha_comm_destroy(comm)
-            return {"ok": False, "error": (lib.aha_comm_last_error().decode() if rc != 0 else "aha_comm_init_rank failed on another rank")}
-        rows = scores_dev.shape[0] * scores_dev.shape[1]
-        loc = scores_dev.contiguous().view(rows, 3)
-        glob = torch.empty((world, rows, 3), dtype=torch.float32, device=scores_dev.device)
-        st = torch.cuda.current_stream().cuda_stream
-        for _ in range(3):
-            lib.aha_allgather_scores(comm, loc.data_ptr(), rows, glob.data_ptr(), st)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            rc = lib.aha_allgather_scores(comm, loc.data_ptr(), rows, glob.data_ptr(), st)
-        torch.cuda.synchronize()
-        us = (time.perf_counter() - t0) / 50 * 1e6
-        want = [torch.empty_like(loc) for _ in range(world)]
-        dist.all_gather(want, loc)
-        ok = rc == 0 and torch.equal(glob, torch.stack(want))
-        lib.aha_comm_destroy(comm)
-        return {"ok": bool(ok), "allgather_us": us, "ranks": world}
-    except Exception as e:                                       # a diagnostic must not take the measurement down
-        return {"ok": False, "error": repr(e)}
 
 
 def all_position_logits_datum(rt, wl, frames_all, F, tf, H, V, headline_ms, sync):
@@ -743,13 +699,68 @@ def sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_st
     return out
 
 
-def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync):
-    """secondary: the per-GPU share of BASELINE configs[3] (64 streams over 8 GPUs): 8 streams batched into every LM step
-    (M = 288 rows per weight pass) on SinkCache(W=2048, sink=32) at steady state, vision encode of 8 x F frames per step."""
+def growing_600_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids):
+    """secondary: SURVEY.md 8d config 2's "DynamicCache-equivalent for 600 frames" - past_key_values=None in the reference
+    (test/inference.py:154-155): the cache only grows, 20 + 35 + 600 x 36 = 21,655 keys at the end, 1.24 GB of K/V read per LM step.
+    One stream, every frame scored in order (vision in batches of 32); the attention roofline is taken on the last frames, where K/V -
+    not the weights' share of a launch - is the HBM term."""
+    F, tf, H = a.frames, cfg.frame_num_tokens, cfg.lm.hidden_size
+    n_frames = 600
+    st = rt.open_stream(None, capacity=cfg.lm.max_position_embeddings)
+    rt.lm_step([st], rt.embed_tokens(query_ids).view(1, -1, H))
+    pre = rt.embed_tokens(prefix_ids).view(1, -1, H)
+    scores = torch.empty((n_frames, 3), dtype=torch.float32, device=dev)
+    host = torch.empty((n_frames, 3), dtype=torch.float32).pin_memory()
+
+    class _W:                                                      # what timed_kind needs
+        streams = [st]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tail_ms = None
+    for i0 in range(0, n_frames, F):
+        n = min(F, n_frames - i0)
+        emb = rt.visual_embed(frames_all[:n]).view(n, tf, H)
+        last = i0 + n >= n_frames
+        if last:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for j in range(n):
+            x = emb[j:j + 1] if i0 + j else torch.cat([pre, emb[:1]], 1).contiguous()
+            rt.lm_step([st], x, out=scores[i0 + j:i0 + j + 1])
+        if last:
+            e1.record()
+    host.copy_(scores, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tail_ms = e0.elapsed_time(e1) / n
+    assert torch.isfinite(host).all() and st.get_seq_length() == 20 + 35 + n_frames * tf
+    # attention at the final length (the timed steps append 36 keys each: 21.7k keys)
+    emb = rt.visual_embed(frames_all[:F]).view(1, F, tf, H)
+    a_ms, a_n, a_by = timed_kind(rt, _W, emb, 4, n_steps=2)
+    wb, kvb, fl = rt.last_step_work()
+    out = {"workload": f"1 stream, growing cache (past_key_values=None), {n_frames} frames scored in order: {st.get_seq_length()} keys at the end",
+           "frames_per_s": n_frames / dt, "ms_total": dt * 1e3, "lm_step_ms_last_batch": tail_ms, "keys_at_end": st.get_seq_length(),
+           "kv_bytes_per_step_at_end": kvb, "weight_bytes_per_step": wb,
+           "lm_step_hbm_frac_at_end": (wb + kvb) / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "roofline_attention": roofline_hbm("cache attention + combine at ~21.7k keys (one layer: K and V of 4 KV heads read once)", a_ms, a_n, a_by)}
+    st.close()
+    return out
+
+
+def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, vit_stream, sync, rank=0, world=1, dist=None, backend="nccl"):
+    """The per-GPU share of BASELINE configs[3] (64 streams over 8 GPUs): 8 streams batched into every LM step (M = 288 rows per
+    weight pass) on SinkCache(W=2048, sink=32) at steady state, vision encode of 8 x F frames per step.  One rank: a secondary
+    datum.  More than one rank: every rank runs its 8 streams (stream g of the node lives on rank g % world), each step's [F, 8, 3]
+    score rows are all-gathered with RCCL underneath the next step, and the time is barrier-bracketed and max-reduced like `value`."""
+    from aha_amd.sharding import gather_scores_async
     from aha_amd.synth import make_frames
     F, tf = a.frames, cfg.frame_num_tokens
-    frames8 = torch.cat([make_frames(F, cfg.vision.image_size, seed=2000 + s).to(dev) for s in range(B2)], 0)
-    wl = Workload(rt, cfg, dev, B2, F, "default_sink", 2048, 32, frames8, prefix_ids, query_ids, main_stream, vit_stream)
+    frames8 = torch.cat([make_frames(F, cfg.vision.image_size, seed=2000 + 100 * rank + s).to(dev) for s in range(B2)], 0)
+    gather = None
+    if world > 1:
+        def gather(scores_dev):
+            return gather_scores_async(scores_dev if backend == "nccl" else scores_dev.cpu(), B2 * world)
+    wl = Workload(rt, cfg, dev, B2, F, "default_sink", 2048, 32, frames8, prefix_ids, query_ids, main_stream, vit_stream, gather)
     fill = -(-(2048 // tf + 2) // F)
     wl.run(fill)
     sync()
@@ -759,18 +770,50 @@ def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, 
     wl.run(steps)
     sync()
     dt = time.perf_counter() - t0
+    ag_us = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        assert wl.last_global.shape == (F, B2 * world, 3) and torch.isfinite(wl.last_global).all()
+        for _ in range(5):
+            gather(wl.scores_dev).result()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            gather(wl.scores_dev).result()
+        torch.cuda.synchronize()
+        ag_us = (time.perf_counter() - t1) / 50 * 1e6
     assert torch.isfinite(wl.scores_host).all()
     emb = wl.last_emb(steps)
     g_ms, g_n, g_by = timed_kind(rt, wl, emb, 2, n_steps=2)
+    a_ms, a_n, a_by = timed_kind(rt, wl, emb, 4, n_steps=2)
+    wb, kvb, fl = rt.last_step_work()
     M = B2 * tf
     flops = 2.0 * M * (2 * cfg.lm.intermediate_size) * cfg.lm.hidden_size
     tf_s = flops / ((g_ms / g_n) * 1e-3) / 1e12 if g_n else None
+    # LM step on its own (graph replay, HIP events) and against both roofs: the step's algorithmic flops and bytes
+    emb_v = emb.view(B2, F, tf, cfg.lm.hidden_size)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(F):
+        rt.lm_step(wl.streams, emb_v[:, i].contiguous(), out=wl.scores_dev[i])
+    e1.record()
+    e1.synchronize()
+    lm_ms = e0.elapsed_time(e1) / F
     # the GEMM does not read the cache: its counter row from the 8-stream static run is the same launch (same M, same weights)
-    rl = roofline_hbm("gemm_wl_bal18_kernel (gate/up + SwiGLU at M = 288 rows)", g_ms, g_n, g_by, "gemm_wl_bal18_kernel", "static_8stream")
+    rl = roofline_hbm("gate/up + SwiGLU at M = 288 rows", g_ms, g_n, g_by, "gemm_wl_bal18_kernel", "static_8stream")
     rl.update({"mfma_achieved_TFLOPs": tf_s, "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS, "mfma_frac": tf_s / MFMA_PEAK_TFLOPS if tf_s else None,
                "flops_per_launch": flops, "note": "arithmetic intensity ~288 flop/B sits on the ridge (312): both fractions are reported"})
-    out = {"workload": f"{B2} streams/GPU, SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step (M = {M} rows per LM step)",
-           "frames_per_s": B2 * F * steps / dt, "ms_per_step": dt / steps * 1e3, "roofline_gate_up": rl}
+    out = {"workload": f"configs[3] per-GPU share: {B2} streams/GPU x {world} GPU(s), SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step "
+                       f"(M = {M} rows per LM step)" + (", RCCL all-gather of the score rows" if world > 1 else ""),
+           "frames_per_s": world * B2 * F * steps / dt, "ms_per_step": dt / steps * 1e3, "n_gpus": world, "streams_total": B2 * world,
+           "allgather_us": ag_us, "lm_step_ms": lm_ms,
+           "lm_step_mfma_frac": (fl / (lm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if fl else None,
+           "lm_step_hbm_frac": (wb + kvb) / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "roofline_gate_up": rl,
+           "roofline_attention": roofline_hbm("cache attention (+ combine) at 8 streams x 2,048 keys (one layer)", a_ms, a_n, a_by)}
     wl.close()
     return out
 

@@ -12,7 +12,7 @@ import torch
 
 from conftest import GOLDEN, HAVE_REFERENCE, ROOT
 
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))       # make_golden.py lives beside this file
 import make_golden as mg  # noqa: E402
 from oracle.cache_policies import SinkPolicy, SlidingPolicy, StaticPolicy, GrowingPolicy, make_policy  # noqa: E402
 
