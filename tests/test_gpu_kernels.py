@@ -302,7 +302,7 @@ def test_attention_over_the_cache_flat_bound(op_rt, case):
     targets = sorted({j for j in edge if 0 <= j < Lk})
     q = _probe_queries(K, T, G, targets, g)
     exact, pav = _attention_exact(q.view(T, d.heads, D), K, V, min(off, 1 << 20), scale)
-    for split_len in (64, 256, 2048):
+    for split_len in (0, 64, 256, 2048):            # 0: the step's own geometry
         got = rt.attention([st], q.view(1, T, -1), 0, causal_off=[off], split_len=split_len)[0]
         e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pav)
         _note(f"attention {case} split_len={split_len} Lk={Lk}", e)
@@ -336,6 +336,50 @@ def test_both_lm_attention_kernels_give_a_row_the_same_bits(op_rt, case):
     finally:
         rt.set_tuning("attn_lm", 1)
     st.close()
+
+
+@pytest.mark.parametrize("Lk_target", [8192, 21655])
+def test_attention_over_a_long_growing_cache_flat_bound(Lk_target):
+    """past_key_values=None in the reference: the cache only grows (test/inference.py:154-155); SURVEY.md 8d config 2 asks for 600
+    frames = 20 + 35 + 600 x 36 = 21,655 keys.  Same flat bound as the 2,048-key cases, probe rows on single keys at the first /
+    last keys, at every key-split edge (256-key splits become 16 long ones at this length: the combine kernels hold one value per
+    split; also 8 splits) and at the 64-key block edges around them; both LM attention kernels give the same bits there too."""
+    from aha_amd.runtime import Runtime
+    cfg = LiveConfig(vision=VisionConfig(image_size=56, patch_size=14, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                                         intermediate_size=256),
+                     lm=LMConfig(num_hidden_layers=1, vocab_size=512), video_pooling_stride=2, name="op7b_long")
+    rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16, jitter=True), max_step_tokens=320, max_vit_frames=1,
+                 max_positions=22016)
+    d = rt.desc
+    T, G, D = 36, d.heads // d.kv_heads, d.head_dim
+    g = _gen(77 + Lk_target)
+    st = rt.open_stream(None, capacity=22016)
+    _fill(rt, st, Lk_target, g)
+    Lk = st.get_seq_length()
+    assert Lk == Lk_target
+    K, V = st.export_kv(0), st.export_kv(0, True)
+    own = -(-(-(-Lk // 8)) // 64) * 64                                  # the fused kernel's split length at one stream: 8 splits
+    forced = -(-(-(-Lk // 16)) // 64) * 64                              # 256-key splits capped at 16
+    edge = [0, 1, Lk - 1, Lk - 2, Lk - T, Lk - T - 1, Lk - T + 1]
+    for sl in (own, forced):
+        for e0 in range(sl, Lk, sl):
+            edge += [e0 - 65, e0 - 64, e0 - 1, e0, e0 + 1, e0 + 63, e0 + 64]
+    targets = sorted({j for j in edge if 0 <= j < Lk})
+    q = _probe_queries(K, T, G, targets, g)
+    exact, pav = _attention_exact(q.view(T, d.heads, D), K, V, Lk - T, D ** -0.5)
+    for split_len in (0, own):
+        got = rt.attention([st], q.view(1, T, -1), 0, causal_off=[Lk - T], split_len=split_len)[0]
+        e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pav)
+        _note(f"attention growing Lk={Lk} split_len={split_len}", e)
+        assert e.max().item() <= 1.0 + 1e-6, (Lk, split_len, e.max().item())
+    out = {}
+    for mode in (0, 2):
+        rt.set_tuning("attn_lm", mode)
+        out[mode] = rt.attention([st], q.view(1, T, -1), 0, causal_off=[Lk - T]).clone()
+    rt.set_tuning("attn_lm", 1)
+    assert torch.equal(out[0], out[2])
+    st.close()
+    rt.close()
 
 
 def test_fused_static_finish_and_attention_matches_the_tile_kernels(op_rt):

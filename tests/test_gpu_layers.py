@@ -158,6 +158,7 @@ def test_tail_final_norm_and_heads_flat_bounds_and_score_fraction(full):
     print(f"teacher-forced last layer + norm + heads: worst raw-logit distance {worst2:.2f} ulp at unit scale; "
           f"scores within 1e-3: {torch.stack(within).mean().item() * 100:.0f} %")
     assert worst2 <= 2.0 + 1e-6
+    assert torch.stack(within).min().item() == 1.0, "teacher-forced tail: every informative / relevance score within the flat 1e-3"
     # (3) free-running report
     fs, ws = torch.stack(free_scores), torch.stack(want_scores)
     frac = ((fs - ws).abs()[:, :2] <= 1e-3).float().mean().item()
