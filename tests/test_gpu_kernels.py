@@ -173,6 +173,14 @@ def test_gemm_tile_within_one_ulp(op_rt, mode):
                 assert e.max().item() <= 0.5 + 1e-3, ("gelu_erf", M, N, K, e.max().item())
                 yr = rt.linear_tile(x, w, bias, residual=res)
                 assert torch.equal(yr, (res.float() + y.float()).bfloat16())
+        # K = 128 is the smallest K the tiled path takes; the persistent 288 x 256 kernel needs four k-steps per tile for its
+        # bias line to land (aha_gemm_tile_p288_ok now says so), so this ragged, biased shape must come out right on EVERY variant
+        x = torch.randn(1731, 128, generator=g, device="cuda").bfloat16()
+        w = (torch.randn(1000, 128, generator=g, device="cuda") * 0.05).bfloat16()
+        bias = torch.randn(1000, generator=g, device="cuda").bfloat16()
+        y = rt.linear_tile(x, w, bias)
+        e = ulp_error(y, x.double() @ w.double().T + bias.double(), slack=1e-5 * (x.float().abs() @ w.float().abs().T))
+        assert e.max().item() <= 0.5 + 1e-6, ("K=128 ragged tile with bias", mode, e.max().item())
     finally:
         rt.set_tuning("tile_dma", 1)
 

@@ -267,3 +267,39 @@ def test_background_tower_kernels_give_the_same_embeddings(vit_l):
                 assert torch.equal(rt.visual_embed(fr), ref), (n, mode)
         finally:
             rt.set_tuning("tower_bg", 0)
+
+
+def test_background_tower_on_72_wide_heads_gives_the_same_embeddings(so400m):
+    """head dims 65..96 run their own dense template, which has no background form - with tower_bg set they take the
+    128-wide template's (zero padding is exact, so the bits cannot depend on the choice).  so400m geometry: 729 keys x 16 heads of 72."""
+    cfg, _, rt = so400m
+    from aha_amd.synth import make_frames
+    fr = make_frames(2, cfg.vision.image_size, seed=21).cuda()
+    ref = rt.visual_embed(fr).clone()
+    try:
+        rt.set_tuning("tower_bg", 1)
+        assert torch.equal(rt.visual_embed(fr), ref)
+    finally:
+        rt.set_tuning("tower_bg", 0)
+
+
+def test_pool_and_layernorm_operators_refuse_shapes_their_kernels_cannot_serve(vit_l):
+    """aha_pool_forward works in 8-channel chunks and, for avg / max pooling, reads rows (oy*stride + dy): channel counts
+    that are not multiples of 8, a non-positive stride or a window that leaves the grid are refused, not executed; aha_layernorm_forward
+    refuses row strides below the row length or off the 16-byte grid."""
+    from aha_amd.runtime import AhaError
+    import ctypes as C
+    cfg, _, rt = vit_l
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 24 * 24, 16, device="cuda", dtype=torch.bfloat16)
+    for ch, grid, out_grid, stride, mode in ((12, 24, 6, 4, 0), (4, 24, 6, 4, 1), (16, 24, 6, 0, 1), (16, 24, 7, 4, 2), (16, 24, 25, 1, 0), (16, 24, 25, 1, 3)):
+        xs = torch.zeros(1, grid * grid, ch, device="cuda", dtype=torch.bfloat16)
+        with pytest.raises(AhaError):
+            rt.pool(xs, grid, out_grid, stride, mode)
+    assert rt.pool(x, 24, 6, 4, 1).shape == (1, 36, 16)              # the valid neighbour of those calls still runs
+    w = torch.ones(64, device="cuda", dtype=torch.bfloat16)
+    xin, out = torch.zeros(4, 64, device="cuda", dtype=torch.bfloat16), torch.zeros(4, 64, device="cuda", dtype=torch.bfloat16)
+    for ldx, ldo in ((32, 64), (64, 56), (68, 64), (64, 60)):
+        rc = rt.lib.aha_layernorm_forward(rt.ctx, xin.data_ptr(), ldx, w.data_ptr(), w.data_ptr(), out.data_ptr(), ldo, 4, 64, C.c_float(1e-6), st)
+        assert rc != 0, (ldx, ldo)
+    assert rt.lib.aha_layernorm_forward(rt.ctx, xin.data_ptr(), 64, w.data_ptr(), w.data_ptr(), out.data_ptr(), 64, 4, 64, C.c_float(1e-6), st) == 0
