@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;      // one 16x16 MFMA 
 
 #define AHA_WAVE 64
 #define AHA_MAX_B 16            // streams batched in one lm_step
+#define AHA_MAX_KEY_SPLITS 64    // key splits of the cache attention (the combine kernels merge them in chunks of 16)
 
 static __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 static __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }

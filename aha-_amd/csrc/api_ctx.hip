@@ -52,7 +52,8 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     c->partial_floats = 16 * M * (nqkv > H ? nqkv : H);       // up to 16 split-K slabs
     if ((rc = dalloc(c, &c->partial, c->partial_floats))) return rc;
     const size_t rows_pad = (size_t)G * M + 16 * AHA_MAX_B;
-    c->part_o_floats = (size_t)d->kv_heads * 16 * rows_pad * Dh;   // up to 16 key splits
+    c->attn_rows_pad = rows_pad;
+    c->part_o_floats = (size_t)d->kv_heads * 16 * rows_pad * Dh;   // 16 key splits of a full step; more (up to AHA_MAX_KEY_SPLITS) for smaller batches: attn_geometry
     if ((rc = dalloc(c, &c->part_o, c->part_o_floats))) return rc;
     if ((rc = dalloc(c, &c->part_ml, (size_t)d->kv_heads * 16 * rows_pad * 2))) return rc;
     if ((rc = dalloc(c, &c->logits, (size_t)AHA_MAX_B * d->vocab))) return rc;

@@ -89,7 +89,7 @@ struct aha_ctx {
     // LM workspaces
     bf16 *h = nullptr, *xn = nullptr, *q_rot = nullptr, *attn_out = nullptr, *act = nullptr;
     float *partial = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *heads_tmp = nullptr;
-    size_t partial_floats = 0, part_o_floats = 0;
+    size_t partial_floats = 0, part_o_floats = 0, attn_rows_pad = 0;   // attn_rows_pad: partial rows the attention buffers hold per (kv head, 1/16 of them)
     int last_B = 0, last_T = 0;
     // ViT workspaces
     bf16 *v_a0 = nullptr, *v_x = nullptr, *v_h = nullptr, *v_qkv = nullptr, *v_attn = nullptr, *v_f = nullptr,
@@ -179,6 +179,7 @@ int plan_stream(aha_ctx* c, aha_stream* s, int T, StreamStep* o);               
 hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ldw, int N, int K, bf16* C, int ldc, const bf16* bias, int act,
                      const bf16* residual, int ldr, const bf16* rowadd, int period, int ldra, hipStream_t st);      // api_vision.hip
 int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st);                                 // api_vision.hip
+void attn_geometry(const aha_ctx* c, int B, int T, int max_lk, int split_override, int* split_len_out, int* n_splits_out);   // api_lm.hip
 int pick_split(aha_ctx* c, int kind, const PackedW& w, int M, int nt_per_wave);                    // api_lm.hip
 int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& w, int epi, int S, float* partial, int ldp, bf16* out, int ldo,
             float* outf, int ldof, hipStream_t st, int kb = 0);                                    // api_lm.hip

@@ -105,6 +105,31 @@ int ws_gemm(aha_ctx* c, int kind, const bf16* X, int ldx, int M, const PackedW& 
     return 0;
 }
 
+// Key-split geometry of the cache attention (launch shape only: the kernels read the key counts from the device descriptor).
+// 256-key splits until there are more than the cap allows, then whole 64-key blocks spread evenly.  The cap: what the partial buffers
+// hold for this batch (they are sized for 16 splits of a full step), at most AHA_MAX_KEY_SPLITS, and - unless the caller forces a
+// split length - no more than gives every CU about four of attn_fwd_kernel's workgroups (a long growing cache at one stream: 64
+// splits, round 4 - 16 left a 21.6k-key cache on 256 workgroups of 22 dependent blocks each; 8 streams: 16, as before).
+void attn_geometry(const aha_ctx* c, int B, int T, int max_lk, int split_override, int* split_len_out, int* n_splits_out) {
+    const aha_model_desc& d = c->d;
+    const int G = d.heads / d.kv_heads, RT = ceil_div(G * T, 16);
+    const int forced = split_override > 0 ? split_override : c->attn_split_len;
+    int split_len = forced > 0 ? round_up(forced, 64) : 256;
+    int n_splits = ceil_div(max_lk, split_len);
+    long cap = (long)(16 * c->attn_rows_pad) / ((long)B * RT * 16);
+    if (cap > AHA_MAX_KEY_SPLITS) cap = AHA_MAX_KEY_SPLITS;
+    if (forced <= 0) {
+        const long fill = (4L * c->n_cus) / ((long)d.kv_heads * ceil_div(RT, 4) * B);
+        const long want = fill > 16 ? fill : 16;
+        if (cap > want) cap = want;
+    }
+    if (cap < 1) cap = 1;
+    if (n_splits > cap) { split_len = round_up(ceil_div(max_lk, (int)cap), 64); n_splits = ceil_div(max_lk, split_len); }
+    if (n_splits < 1) n_splits = 1;
+    *split_len_out = split_len;
+    *n_splits_out = n_splits;
+}
+
 extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
                            float* out_raw, void* out_last_hidden, aha_hip_stream st_) {
     if (!c || !streams || !embeds) return AHA_E_INVAL;
@@ -211,10 +236,8 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     }
 
     // attention geometry (launch shape only: the kernels read the key counts from the device descriptor)
-    int split_len = c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256;
-    int n_splits = ceil_div(max_lk, split_len);
-    if (n_splits > 16) { split_len = round_up(ceil_div(max_lk, 16), 64); n_splits = ceil_div(max_lk, split_len); }
-    if (n_splits < 1) n_splits = 1;
+    int split_len, n_splits;
+    attn_geometry(c, B, T, max_lk, 0, &split_len, &n_splits);
 
     // Every stream of the step a frozen TrulyStaticCache: the new tokens' K/V are neither stored nor read
     // (test/static_cache.py:33-36).  By default the full q|k|v projection still runs, as in the reference (its K/V columns

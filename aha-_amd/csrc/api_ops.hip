@@ -131,9 +131,8 @@ extern "C" int aha_attention_forward(aha_ctx* c, aha_stream* const* streams, int
     }
     int rc = upload_desc(c, sd, st);
     if (rc) return rc;
-    int sl = split_len > 0 ? round_up(split_len, 64) : (c->attn_split_len > 0 ? round_up(c->attn_split_len, 64) : 256);
-    int ns = ceil_div(max_lk, sl);
-    if (ns > 16) { sl = round_up(ceil_div(max_lk, 16), 64); ns = ceil_div(max_lk, sl); }
+    int sl, ns;
+    attn_geometry(c, B, T, max_lk, split_len, &sl, &ns);            // the choice aha_lm_step makes for this shape (or the forced length)
     const int QD = d.heads * d.head_dim;
     AttnArgs a;
     memset(&a, 0, sizeof(a));

@@ -915,32 +915,46 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
-    // every load of every split is independent of the running maximum: issue them all at once (at most 16 splits, the
-    // launcher's cap), then reduce in split order - one memory round trip instead of two dependent ones per split
-    float m_[16], l_[16];
-    f32x4 p0[16], p1[16];
+    // Splits are merged in chunks of 16: every load of a chunk is independent of the running maximum, so they are issued at once (one
+    // memory round trip per chunk), then reduced in split order.  Up to 16 splits (every cache shorter than 4,096 keys) this is ONE
+    // chunk and the arithmetic of rounds 1-3; longer caches (round 4: up to 64 splits, so that a 21.6k-key cache spreads over the
+    // whole chip) carry (M, L, acc) from chunk to chunk, rescaled when the maximum moves - the online-softmax merge once more.
+    float M = -INFINITY, L = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < ns; s0 += 16) {
+        float m_[16], l_[16];
+        f32x4 p0[16], p1[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) {
-            const long prow = (base + s) * Rpad + r;
-            m_[s] = a.part_ml[prow * 2];
-            l_[s] = a.part_ml[prow * 2 + 1];
-            p0[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0);
-            p1[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) {
+                const long prow = (base + s0 + s) * Rpad + r;
+                m_[s] = a.part_ml[prow * 2];
+                l_[s] = a.part_ml[prow * 2 + 1];
+                p0[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0);
+                p1[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+            }
+        float Mc = M;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) Mc = fmaxf(Mc, m_[s]);
+        if (s0 > 0) {                                            // a later chunk: bring the running sums to the new maximum
+            const float sc = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(M - Mc);
+            L *= sc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= sc;
         }
-    float M = -INFINITY;
+        M = Mc;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) M = fmaxf(M, m_[s]);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) {
+                const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima live in the base-2 domain
+                // explicit FMAs: with the chunk rescale in front, "acc * sc + w * p" leaves the compiler a choice of which product to fuse
+                // with the add, and the two combine kernels must make the same one (a row gets the same bits from either)
+                L = __builtin_fmaf(w, l_[s], L);
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) {
-            const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima live in the base-2 domain
-            L += w * l_[s];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[e] += w * p0[s][e]; acc[4 + e] += w * p1[s][e]; }
-        }
+                for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(w, p0[s][e], acc[e]); acc[4 + e] = __builtin_fmaf(w, p1[s][e], acc[4 + e]); }
+            }
+    }
     const int g = r / a.T, t = r % a.T;
     bf16x8 ov;
 #pragma unroll
@@ -956,28 +970,36 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
-    // all loads first (independent of the maximum; at most 16 splits), then the reduction in split order
-    float m_[16], l_[16], p_[16];
+    // chunks of 16 splits, all loads of a chunk first, reduction in split order; same arithmetic as attn_combine16_kernel
+    float M = -INFINITY, L = 0.f, acc = 0.f;
+    for (int s0 = 0; s0 < ns; s0 += 16) {
+        float m_[16], l_[16], p_[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) {
-            const long prow = (base + s) * Rpad + r;
-            m_[s] = a.part_ml[prow * 2];
-            l_[s] = a.part_ml[prow * 2 + 1];
-            p_[s] = a.part_o[prow * D + d];
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) {
+                const long prow = (base + s0 + s) * Rpad + r;
+                m_[s] = a.part_ml[prow * 2];
+                l_[s] = a.part_ml[prow * 2 + 1];
+                p_[s] = a.part_o[prow * D + d];
+            }
+        float Mc = M;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) Mc = fmaxf(Mc, m_[s]);
+        if (s0 > 0) {
+            const float sc = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(M - Mc);
+            L *= sc;
+            acc *= sc;
         }
-    float M = -INFINITY;
+        M = Mc;
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) M = fmaxf(M, m_[s]);
-    float acc = 0.f, L = 0.f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-        if (s < ns) {
-            const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima are kept in the base-2 domain
-            L += w * l_[s];
-            acc += w * p_[s];
-        }
+        for (int s = 0; s < 16; ++s)
+            if (s0 + s < ns) {
+                const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima are kept in the base-2 domain
+                L = __builtin_fmaf(w, l_[s], L);               // explicit FMAs, as in attn_combine16_kernel
+                acc = __builtin_fmaf(w, p_[s], acc);
+            }
+    }
     const int g = r / a.T, t = r % a.T;
     if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(L > 0.f ? acc / L : 0.f);
 }
@@ -1079,7 +1101,7 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
 // channels zero-padded on chip (so400m: 72 -> 96).
 extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int B, int head_dim, hipStream_t st) {
     if (!sd && a_->n_splits != 1) return hipErrorInvalidValue;
-    if (a_->n_splits < 1 || a_->n_splits > 16) return hipErrorInvalidValue;      // the combine kernels hold one value per split in registers
+    if (a_->n_splits < 1 || a_->n_splits > AHA_MAX_KEY_SPLITS) return hipErrorInvalidValue;   // partial buffers are sized for this many
     if (head_dim < 8 || head_dim > 128 || (head_dim & 7)) return hipErrorInvalidValue;
     AttnArgs a = *a_;
     a.hd = head_dim;

@@ -117,7 +117,7 @@ def pmc_traffic(kernel_prefix, workload):
     process being measured) - only from a counter run of the SAME workload as the timed one: a summary row carries the
     workload it was collected on ("static_1stream", "static_8stream", "sink_1stream_steady", "sink_8stream_steady"); rows of any
     other workload, or a summary that does not say, give None."""
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

@@ -350,8 +350,8 @@ def test_both_lm_attention_kernels_give_a_row_the_same_bits(op_rt, case):
 def test_attention_over_a_long_growing_cache_flat_bound(Lk_target):
     """past_key_values=None in the reference: the cache only grows (test/inference.py:154-155); SURVEY.md 8d config 2 asks for 600
     frames = 20 + 35 + 600 x 36 = 21,655 keys.  Same flat bound as the 2,048-key cases, probe rows on single keys at the first /
-    last keys, at every key-split edge (256-key splits become 16 long ones at this length: the combine kernels hold one value per
-    split; also 8 splits) and at the 64-key block edges around them; both LM attention kernels give the same bits there too."""
+    last keys and on a sweep of key-split edges of both geometries (the step's own: up to 64 splits, merged in chunks of 16 by the
+    combine kernels; and 1,408-key splits) with the 64-key block edges around them; both LM attention kernels give the same bits."""
     from aha_amd.runtime import Runtime
     cfg = LiveConfig(vision=VisionConfig(image_size=56, patch_size=14, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
                                          intermediate_size=256),
@@ -366,16 +366,17 @@ def test_attention_over_a_long_growing_cache_flat_bound(Lk_target):
     Lk = st.get_seq_length()
     assert Lk == Lk_target
     K, V = st.export_kv(0), st.export_kv(0, True)
-    own = -(-(-(-Lk // 8)) // 64) * 64                                  # the fused kernel's split length at one stream: 8 splits
-    forced = -(-(-(-Lk // 16)) // 64) * 64                              # 256-key splits capped at 16
+    own = 256 if Lk <= 64 * 256 else -(-(-(-Lk // 64)) // 64) * 64      # the step's own geometry at one stream: 256-key splits, at most 64 of them
+    forced = 1408                                                       # what rounds 1-3 used at 21.6k keys (16 splits)
     edge = [0, 1, Lk - 1, Lk - 2, Lk - T, Lk - T - 1, Lk - T + 1]
     for sl in (own, forced):
         for e0 in range(sl, Lk, sl):
             edge += [e0 - 65, e0 - 64, e0 - 1, e0, e0 + 1, e0 + 63, e0 + 64]
+    edge = edge[:7] + edge[7::max(1, (len(edge) - 7) // 160)]           # a sweep over the edges (the probe rows are limited)
     targets = sorted({j for j in edge if 0 <= j < Lk})
     q = _probe_queries(K, T, G, targets, g)
     exact, pav = _attention_exact(q.view(T, d.heads, D), K, V, Lk - T, D ** -0.5)
-    for split_len in (0, own):
+    for split_len in (0, forced):
         got = rt.attention([st], q.view(1, T, -1), 0, causal_off=[Lk - T], split_len=split_len)[0]
         e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pav)
         _note(f"attention growing Lk={Lk} split_len={split_len}", e)
