@@ -807,7 +807,7 @@ def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, 
     rl.update({"mfma_achieved_TFLOPs": tf_s, "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS, "mfma_frac": tf_s / MFMA_PEAK_TFLOPS if tf_s else None,
                "flops_per_launch": flops, "note": "arithmetic intensity ~288 flop/B sits on the ridge (312): both fractions are reported"})
     out = {"workload": f"configs[3] per-GPU share: {B2} streams/GPU x {world} GPU(s), SinkCache W=2048 sink=32 at steady state, {F} frames/stream/step "
-                       f"(M = {M} rows per LM step)" + (", RCCL all-gather of the score rows" if world > 1 else ""),
+                       f"(M = {M} rows per LM step)" + (f", {'RCCL' if backend == 'nccl' else 'gloo'} all-gather of the score rows" if world > 1 else ""),
            "frames_per_s": world * B2 * F * steps / dt, "ms_per_step": dt / steps * 1e3, "n_gpus": world, "streams_total": B2 * world,
            "allgather_us": ag_us, "lm_step_ms": lm_ms,
            "lm_step_mfma_frac": (fl / (lm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if fl else None,

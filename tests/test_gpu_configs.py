@@ -541,3 +541,19 @@ def test_bench_launches_ranks_itself_and_the_rccl_path_runs():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     chk = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"ok"')][-1])
     assert chk["ok"] is True and chk["ranks"] == 1 and chk["allgather_us"] > 0, chk
+
+
+def test_bench_two_ranks_emit_the_configs3_datum():
+    """`bench.py --gpus N` with N > 1 also measures the one multi-GPU configuration BASELINE.json names (configs[3]: 8 streams per GPU on
+    SinkCache, score rows all-gathered): rehearsed here with two ranks sharing the card over gloo at the FULL model size (short run), so
+    that the driver's scaling run does not meet that code path for the first time."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                        "--frames", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    e = out["eight_stream_sink"]
+    assert out["n_gpus"] == 2 and out["distributed"]["ranks_seen"] == 2 and out["value"] > 0
+    assert e["n_gpus"] == 2 and e["streams_total"] == 16 and e["frames_per_s"] > 0 and e["allgather_us"] > 0
+    assert out["sink_w2048"] is None and out["growing_600"] is None          # single-GPU secondaries stay out of a multi-rank line
