@@ -742,7 +742,8 @@ def growing_600_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids):
            "frames_per_s": n_frames / dt, "ms_total": dt * 1e3, "lm_step_ms_last_batch": tail_ms, "keys_at_end": st.get_seq_length(),
            "kv_bytes_per_step_at_end": kvb, "weight_bytes_per_step": wb,
            "lm_step_hbm_frac_at_end": (wb + kvb) / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "roofline_attention": roofline_hbm("cache attention + combine at ~21.7k keys (one layer: K and V of 4 KV heads read once)", a_ms, a_n, a_by)}
+           "roofline_attention": roofline_hbm("attn_lm_kernel<128,8> + attn_combine16_kernel at ~21.7k keys (one layer: K and V of 4 KV heads read once; traffic: the attention kernel alone)",
+                                              a_ms, a_n, a_by, "attn_lm_kernel<128, 8>", "growing_1stream_tail")}
     st.close()
     return out
 

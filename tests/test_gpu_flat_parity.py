@@ -13,8 +13,8 @@ profiles/r04_stable_regime_cpu.json), and the bound is the flat one:
 
 Both sides run END TO END and free: the HIP path from uint8 frames through its own tower / projector / pool / 28-layer LM
 on its own cache, the oracle from the same uint8 frames through its own tower and LM - nothing is teacher-forced or shared
-but the frames and the weights.  Policies: TrulyStaticCache (configs[1]) and SinkCache through evictions and re-rotations
-(configs[2]'s policy at a window that 64 frames overflow), plus the growing cache; and configs[4]'s driver flow on two short
+but the frames and the weights.  Policies: TrulyStaticCache (configs[1]), SinkCache through evictions and re-rotations and
+SlidingWindowCache (configs[2]'s policies at a window the frames overflow), the growing cache, 8 streams batched (configs[3]); and configs[4]'s driver flow on two short
 videos (score vectors through LiveInferForBenchmark vs the oracle driver, then the ported metrics).
 
 Heads: `aha_amd.synth.calibrated_heads` - closed-form heads aligned with the three leading frame-to-frame directions of the
@@ -73,7 +73,7 @@ def stable():
     w.update(heads)
     olm.w.update(heads)
     wd.update({k: v.cuda() for k, v in heads.items()})
-    rt = Runtime(cfg, wd, max_step_tokens=160, max_vit_frames=32)
+    rt = Runtime(cfg, wd, max_step_tokens=640, max_vit_frames=32)
     del wd
     torch.cuda.empty_cache()
     frames = make_frames(N_FRAMES, S, seed=4242, tint=True)
@@ -98,7 +98,7 @@ def test_stable_regime_embeddings_are_unit_scale_and_close(stable):
     assert e.max().item() <= 16.0
 
 
-@pytest.mark.parametrize("policy,window,sink", [("static", 2048, 0), ("default_sink", 1024, 32), (None, 0, 0)])
+@pytest.mark.parametrize("policy,window,sink", [("static", 2048, 0), ("default_sink", 1024, 32), ("sliding_window", 1024, 0), (None, 0, 0)])
 def test_free_running_scores_within_flat_1e3_of_the_bf16_oracle(stable, policy, window, sink):
     from oracle.cache_policies import make_policy
     from oracle.qwen2_live import frame_scores
@@ -134,10 +134,52 @@ def test_free_running_scores_within_flat_1e3_of_the_bf16_oracle(stable, policy, 
     print(f"flat parity [{key}]:", json.dumps(STATS[key]))
     _dump()
     assert seq_hip == pol.get_seq_length()
-    if policy == "default_sink":
-        assert seq_hip == window                                   # the window filled and evicted (re-rotations ran)
+    if policy in ("default_sink", "sliding_window"):
+        assert seq_hip == window                                   # the window filled and evicted (SinkCache: re-rotations ran)
     assert want.double().std(0).min().item() >= 0.02, "degenerate scores: the regime must keep a real spread"
     assert d.max().item() <= FLAT_TOL, (d.max(0).values.tolist(), d.argmax(0).tolist())
+
+
+def test_eight_streams_batched_within_flat_1e3_of_the_bf16_oracle(stable):
+    """configs[3]'s per-GPU share at full size: 8 independent streams batched into every LM step (M = 288 rows per weight pass: the
+    mid-M GEMM kernels and the multi-stream attention kernel), SinkCache W = 384 / sink 16 so that every stream evicts and re-rotates from
+    its 10th frame on, 14 frames per stream, each stream held to the flat 1e-3 against its OWN oracle run on the oracle's own embeddings."""
+    from oracle.cache_policies import make_policy
+    from oracle.qwen2_live import frame_scores
+    cfg, rt, olm, emb_hip, emb_ref, _ = stable
+    H, V = cfg.lm.hidden_size, cfg.lm.vocab_size
+    B, n, W, S = 8, 14, 384, 16
+    q_ids, pre_ids = make_token_ids(20, V, seed=101), make_token_ids(35, V, seed=100)
+    idx = [[(7 * s + 3 * i) % N_FRAMES for i in range(n)] for s in range(B)]            # stream s sees its own frame sequence
+    sts = [rt.open_stream("default_sink", W, S) for _ in range(B)]
+    rt.lm_step(sts, rt.embed_tokens(q_ids).view(1, -1, H).expand(B, -1, -1).contiguous())
+    pre = rt.embed_tokens(pre_ids).view(1, -1, H).expand(B, -1, -1)
+    got = torch.empty((n, B, 3), device="cuda")
+    for i in range(n):
+        x = torch.stack([emb_hip[idx[s][i]] for s in range(B)])
+        if i == 0:
+            x = torch.cat([pre, x], 1)
+        rt.lm_step(sts, x.contiguous(), out=got[i])
+    got = got.cpu()
+    assert all(st.get_seq_length() == W for st in sts)
+    for st in sts:
+        st.close()
+    worst = 0.0
+    opre = olm.embed_tokens(pre_ids)
+    for s in range(B):
+        pol = make_policy("default_sink", W, S)
+        olm.step(olm.embed_tokens(q_ids), pol)
+        for i in range(n):
+            x = emb_ref[idx[s][i]][None]
+            if i == 0:
+                x = torch.cat([opre, x], 1)
+            want = frame_scores(olm.step(x, pol))[0]
+            worst = max(worst, (got[i, s].double() - want.double()).abs().max().item())
+        assert pol.get_seq_length() == W
+    STATS["eight_streams_batched"] = {"streams": B, "frames_per_stream": n, "window": W, "sink": S, "max_abs_diff": worst}
+    print("flat parity [8 streams batched]:", json.dumps(STATS["eight_streams_batched"]))
+    _dump()
+    assert worst <= FLAT_TOL, worst
 
 
 def test_growing_cache_to_600_frames_bookkeeping_and_reproducibility(stable):

@@ -32,7 +32,7 @@ if os.environ.get("AHA_DUMP_MAPS"):
 rt.set_tuning("use_graph", use_graph)
 g = torch.Generator(device="cuda").manual_seed(0)
 if policy == "none":
-    sts = [rt.open_stream(None, 0, 0, capacity=4096) for _ in range(B)]
+    sts = [rt.open_stream(None, 0, 0, capacity=max(4096, steps * tf + 64)) for _ in range(B)]      # e.g. 600 steps: 21,600 keys
 else:
     sts = [rt.open_stream(policy, 2048, 32 if policy == "default_sink" else 0) for _ in range(B)]
 x = (torch.randn(B, tf, H, generator=g, device="cuda") * 0.05).bfloat16()

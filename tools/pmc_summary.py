@@ -4,11 +4,12 @@ roofline.traffic:   pmc_summary.py <out.json> <workload>=<fetch_dir>,<write_dir>
 Every row carries the workload it was collected on; bench.py takes `traffic` only from a row of the workload it timed.
 Correction (MI355X_MICROARCH.md, HBM section): the counters are in KB and on gfx950 FETCH_SIZE reports half the bytes of wide
 coalesced reads, so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged per launch of each kernel.  With `steady` in a
-workload's name only the second half of each kernel's dispatches is averaged (the first half fills the cache)."""
+workload's name only the second half of each kernel's dispatches is averaged (the first half fills the cache); with `tail`
+the last 5 % (a growing cache at its final length)."""
 import collections, csv, glob, json, os, sys
 
 
-def per_kernel(d, counter, steady):
+def per_kernel(d, counter, steady, tail=False):
     seq = collections.defaultdict(list)
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
@@ -20,6 +21,8 @@ def per_kernel(d, counter, steady):
         vals = [x for _, x in v]
         if steady and len(vals) >= 4:
             vals = vals[len(vals) // 2:]
+        if tail and len(vals) >= 40:                         # a growing cache: the last 5 % of the dispatches (the cache at its final length)
+            vals = vals[-(len(vals) // 20):]
         out[k] = (len(vals), sum(vals) / len(vals))
     return out
 
@@ -30,8 +33,8 @@ def main():
         wl, rest = spec.split("=", 1)
         parts = rest.split(",", 2)
         cmds[wl] = parts[2] if len(parts) > 2 else ""
-        steady = "steady" in wl
-        fetch, write = per_kernel(parts[0], "FETCH_SIZE", steady), per_kernel(parts[1], "WRITE_SIZE", steady)
+        steady, tail = "steady" in wl, "tail" in wl
+        fetch, write = per_kernel(parts[0], "FETCH_SIZE", steady, tail), per_kernel(parts[1], "WRITE_SIZE", steady, tail)
         for k, (n, f_avg) in fetch.items():
             wn, w_avg = write.get(k, (0, 0.0))
             rows.append({"workload": wl, "kernel": k if len(k) < 160 else k[:157] + "...", "dispatches": n, "FETCH_SIZE_KB_avg": round(f_avg, 1),
