@@ -252,3 +252,64 @@ def test_config4_driver_score_vectors_at_full_size_within_flat_1e3(stable):
     assert all(np.isfinite(x) for x in m_hip)
     ticks = LiveInferForDemo.find_ticks(None, pred["synth_001"], fps=1)
     assert all(0 <= t < 20 for t in ticks)
+
+
+def test_reference_faithful_geometry_within_flat_1e3():
+    """The same flat statement on the REFERENCE-FAITHFUL shapes (models/arguments_live.py:22-24): so400m/14@384 tower
+    (26 layers, width 1152, 16 heads x 72, MLP 4304, 729 patches), bilinear 27 -> 7 pooling = 49 tokens per frame, Qwen2-7B dims.  Its own
+    stable-regime weights and calibrated heads; 20 frames end to end on both sides, TrulyStaticCache and SinkCache (W = 512: evicting from
+    frame 9), every score within 1e-3 of the bf16 oracle."""
+    from aha_amd.runtime import Runtime
+    from aha_amd.synth import calibrated_heads
+    from oracle.cache_policies import GrowingPolicy, make_policy
+    from oracle.qwen2_live import OracleLM, frame_scores
+    from oracle.vision_tower import OracleVision
+    cfg = preset("ref")
+    n, ncal = 20, 16
+    wd = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True, regime="stable")
+    w = {k: v.cpu() for k, v in wd.items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tf, H, S, V = cfg.frame_num_tokens, cfg.lm.hidden_size, cfg.vision.image_size, cfg.lm.vocab_size
+    assert tf == 49 and cfg.vision.head_dim == 72
+    ov, olm = OracleVision(cfg, w, torch.bfloat16), OracleLM(cfg.lm, w, torch.bfloat16)
+    cal = make_frames(ncal, S, seed=778, tint=True)
+    emb_cal = torch.cat([ov.visual_embed(cal[i:i + 4]) for i in range(0, ncal, 4)]).view(ncal, tf, H)
+    hid = torch.stack([olm.step(emb_cal[i:i + 1], GrowingPolicy())["hidden"][0, -1] for i in range(ncal)])
+    heads = calibrated_heads(hid.float())
+    w.update(heads)
+    olm.w.update(heads)
+    wd.update({k: v.cuda() for k, v in heads.items()})
+    rt = Runtime(cfg, wd, max_step_tokens=160, max_vit_frames=32)
+    del wd
+    torch.cuda.empty_cache()
+    frames = make_frames(n, S, seed=4243, tint=True)
+    emb_hip = rt.visual_embed(frames.cuda()).view(n, tf, H)
+    emb_ref = torch.cat([ov.visual_embed(frames[i:i + 4]) for i in range(0, n, 4)]).view(n, tf, H)
+    q_ids, pre_ids = make_token_ids(20, V, seed=101), make_token_ids(35, V, seed=100)
+    out = {}
+    try:
+        for policy, window, sink in (("static", 2048, 0), ("default_sink", 512, 32)):
+            st = rt.open_stream(policy, window, sink)
+            rt.lm_step([st], rt.embed_tokens(q_ids).view(1, -1, H))
+            pre = rt.embed_tokens(pre_ids).view(1, -1, H)
+            got = torch.empty((n, 3), device="cuda")
+            for i in range(n):
+                x = emb_hip[i:i + 1] if i else torch.cat([pre, emb_hip[:1]], 1)
+                rt.lm_step([st], x.contiguous(), out=got[i:i + 1])
+            got = got.cpu()
+            seq_hip = st.get_seq_length()
+            st.close()
+            pol = make_policy(policy, window, sink)
+            olm.step(olm.embed_tokens(q_ids), pol)
+            opre = olm.embed_tokens(pre_ids)
+            want = torch.stack([frame_scores(olm.step(emb_ref[i:i + 1] if i else torch.cat([opre, emb_ref[:1]], 1), pol))[0] for i in range(n)])
+            d = (got.double() - want.double()).abs()
+            out[policy] = {"seq_len": seq_hip, "max_abs_diff": d.max(0).values.tolist(), "score_std": want.double().std(0).tolist()}
+            assert seq_hip == pol.get_seq_length()
+            assert d.max().item() <= FLAT_TOL, (policy, d.max(0).values.tolist())
+            assert want.double().std(0).min().item() >= 0.015
+    finally:
+        STATS["ref_so400m_384"] = out
+        print("flat parity [reference-faithful geometry]:", json.dumps(out))
+        _dump()
+        rt.close()
