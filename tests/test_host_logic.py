@@ -225,3 +225,29 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run-collective"], capture_output=True, text=True,
                         timeout=120, env=env2)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+def test_calibrated_heads_are_centred_aligned_and_scaled():
+    """aha_amd.synth.calibrated_heads (the heads of the flat-1e-3 parity regime): logits of the calibration rows are centred (no response
+    to the rows' common component), the informative pair is antisymmetric, the largest calibration logit equals the requested span, and a
+    coherent feature of the hidden rows comes out with far more spread than a random direction gives at the same logit scale."""
+    import torch
+    from aha_amd.synth import calibrated_heads
+    g = torch.Generator().manual_seed(3)
+    n, H = 24, 256
+    feat = torch.randn(3, H, generator=g)                                   # three coherent directions
+    amp = torch.randn(n, 3, generator=g) * torch.tensor([3.0, 2.0, 1.0])
+    X = 5.0 * torch.randn(H, generator=g)[None] + amp @ feat + 0.3 * torch.randn(n, H, generator=g)     # common component + features + noise
+    spans = (0.3, 0.3, 0.08)
+    hd = calibrated_heads(X, spans=spans, dtype=torch.float32)
+    wi, wr, wu = hd["informative_head.weight"], hd["relevance_head.weight"], hd["uncertainty_head.weight"]
+    assert wi.shape == (2, H) and wr.shape == (1, H) and wu.shape == (1, H)
+    assert torch.allclose(wi[0], -wi[1])
+    mu = X.mean(0)
+    for w, span in ((wi[1] - wi[0], spans[0]), (wr[0], spans[1]), (wu[0], spans[2])):
+        lg = X @ w
+        assert abs(float(mu @ w)) <= 1e-3 * float(mu.norm() * w.norm())      # orthogonal to the mean row
+        assert abs(lg.abs().max().item() - span) <= 1e-4 * span + 1e-6
+        assert lg.std().item() >= 0.25 * span                                # a real spread, not one outlier
+    # the leading head reads the strongest coherent feature
+    assert abs(torch.corrcoef(torch.stack([X @ (wi[1] - wi[0]), amp[:, 0]]))[0, 1].item()) >= 0.9
