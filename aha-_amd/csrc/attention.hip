@@ -902,9 +902,58 @@ __global__ __launch_bounds__(64 * NW) void attn_lm_kernel(AttnArgs a, const Step
     }
 }
 
-// Merge key splits, 16 query rows per 256-thread block: a thread owns 8 output channels of one row (two 16-B partial loads per
-// split, one 16-B store), so the 8,064 tiny blocks of attn_combine_kernel at 8 streams become 512.  Same summation order over
-// the splits as attn_combine_kernel.
+// ---------------------------------------------------------------------------------------------
+// Merging the key splits.  One arithmetic for all three kernels below (a row gets the same bits from any of them):
+//   per CHUNK of 16 splits (in split order):  Mc = max m_s;  w_s = 2^(m_s - Mc);  Lc = fma(w_s, l_s, Lc);  accc = fma(w_s, p_s, accc)
+//   chunks merged in order into (M, L, acc):  Mn = max(M, Mc);  a = 2^(M - Mn), b = 2^(Mc - Mn) (0 for -inf);  L = fma(b, Lc, a L);  acc = fma(b, accc, a acc)
+// Up to 16 splits (every cache below 4,096 keys) that is one chunk and exactly the arithmetic of rounds 1-3 (a = 0, b = 1).  Longer caches
+// (round 4: up to 64 splits so that a 21.6k-key cache spreads over the chip) have 2-4 chunks; the chunk sums are independent of each
+// other, so attn_combine16c_kernel gives each chunk its own threads: one memory round trip for 64 splits instead of four dependent ones
+// (the sequential form took 18.7 us per layer on a 600-frame growing stream, as long as the attention kernel itself).
+// ---------------------------------------------------------------------------------------------
+struct CombChunk8 { float M, L, acc[8]; };
+struct CombChunk1 { float M, L, acc; };
+
+template <int D>
+static __device__ __forceinline__ CombChunk8 comb_chunk8(const AttnArgs& a, long base, int Rpad, int r, int d0, int s0, int ns) {
+    float m_[16], l_[16];
+    f32x4 p0[16], p1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s0 + s < ns) {                                         // every load of the chunk is issued before the first is used
+            const long prow = (base + s0 + s) * Rpad + r;
+            m_[s] = a.part_ml[prow * 2];
+            l_[s] = a.part_ml[prow * 2 + 1];
+            p0[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0);
+            p1[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
+        }
+    CombChunk8 c;
+    c.M = -INFINITY; c.L = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c.acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s0 + s < ns) c.M = fmaxf(c.M, m_[s]);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        if (s0 + s < ns) {
+            const float w = c.M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - c.M);    // running maxima live in the base-2 domain
+            c.L = __builtin_fmaf(w, l_[s], c.L);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c.acc[e] = __builtin_fmaf(w, p0[s][e], c.acc[e]); c.acc[4 + e] = __builtin_fmaf(w, p1[s][e], c.acc[4 + e]); }
+        }
+    return c;
+}
+static __device__ __forceinline__ void comb_merge(float& M, float& L, float* acc, int n, float Mc, float Lc, const float* accc) {
+    const float Mn = fmaxf(M, Mc);
+    const float fa = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(M - Mn), fb = Mc == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(Mc - Mn);
+    L = __builtin_fmaf(fb, Lc, fa * L);
+    for (int e = 0; e < n; ++e) acc[e] = __builtin_fmaf(fb, accc[e], fa * acc[e]);
+    M = Mn;
+}
+
+// 16 query rows per 256-thread block: a thread owns 8 output channels of one row (two 16-B partial loads per split, one 16-B store), so
+// the 8,064 tiny blocks of attn_combine_kernel at 8 streams become 512.  Chunks one after the other: the form for up to 16 splits.
 template <int D>
 __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
     static_assert(D == 128, "16 threads x 8 channels per row");
@@ -915,45 +964,11 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
-    // Splits are merged in chunks of 16: every load of a chunk is independent of the running maximum, so they are issued at once (one
-    // memory round trip per chunk), then reduced in split order.  Up to 16 splits (every cache shorter than 4,096 keys) this is ONE
-    // chunk and the arithmetic of rounds 1-3; longer caches (round 4: up to 64 splits, so that a 21.6k-key cache spreads over the
-    // whole chip) carry (M, L, acc) from chunk to chunk, rescaled when the maximum moves - the online-softmax merge once more.
     float M = -INFINITY, L = 0.f;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < ns; s0 += 16) {
-        float m_[16], l_[16];
-        f32x4 p0[16], p1[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (s0 + s < ns) {
-                const long prow = (base + s0 + s) * Rpad + r;
-                m_[s] = a.part_ml[prow * 2];
-                l_[s] = a.part_ml[prow * 2 + 1];
-                p0[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0);
-                p1[s] = *reinterpret_cast<const f32x4*>(a.part_o + prow * D + d0 + 4);
-            }
-        float Mc = M;
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (s0 + s < ns) Mc = fmaxf(Mc, m_[s]);
-        if (s0 > 0) {                                            // a later chunk: bring the running sums to the new maximum
-            const float sc = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(M - Mc);
-            L *= sc;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] *= sc;
-        }
-        M = Mc;
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-            if (s0 + s < ns) {
-                const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima live in the base-2 domain
-                // explicit FMAs: with the chunk rescale in front, "acc * sc + w * p" leaves the compiler a choice of which product to fuse
-                // with the add, and the two combine kernels must make the same one (a row gets the same bits from either)
-                L = __builtin_fmaf(w, l_[s], L);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { acc[e] = __builtin_fmaf(w, p0[s][e], acc[e]); acc[4 + e] = __builtin_fmaf(w, p1[s][e], acc[4 + e]); }
-            }
+        const CombChunk8 c = comb_chunk8<D>(a, base, Rpad, r, d0, s0, ns);
+        comb_merge(M, L, acc, 8, c.M, c.L, c.acc);
     }
     const int g = r / a.T, t = r % a.T;
     bf16x8 ov;
@@ -962,7 +977,43 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
 }
 
-// Merge key splits: one block of D threads per (b, kv head, row).
+// More than 16 splits: 4 query rows per 256-thread block, the (up to four) chunks of a row on different threads - every partial load of
+// the row is in flight at once - then merged in chunk order through LDS.
+template <int D>
+__global__ __launch_bounds__(256) void attn_combine16c_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
+    static_assert(D == 128 && AHA_MAX_KEY_SPLITS <= 64, "16 threads x 8 channels per row, four chunks of 16 splits");
+    __shared__ float sm[4][4][16][10];                              // [row][chunk][channel group][M, L, acc 0..7]
+    const int R = a.G * a.T, RT = ceil_div(R, 16), Rpad = RT * 16;
+    const int rl = threadIdx.x >> 6, ch = (threadIdx.x >> 4) & 3, cg = threadIdx.x & 15;
+    const int r = blockIdx.x * 4 + rl, d0 = cg * 8;
+    const int hk = blockIdx.y, b = blockIdx.z;
+    const int Lk = sdp->s[b].len_after;
+    const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
+    const long base = ((long)b * a.Hkv + hk) * a.n_splits;
+    const int rc = min(r, R - 1);
+    if (ch * 16 < ns) {
+        const CombChunk8 c = comb_chunk8<D>(a, base, Rpad, rc, d0, ch * 16, ns);
+        float* o = sm[rl][ch][cg];
+        o[0] = c.M; o[1] = c.L;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[2 + e] = c.acc[e];
+    }
+    __syncthreads();
+    if (ch != 0 || r >= R) return;
+    float M = -INFINITY, L = 0.f;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c * 16 < ns; ++c) {
+        const float* o = sm[rl][c][cg];
+        comb_merge(M, L, acc, 8, o[0], o[1], o + 2);
+    }
+    const int g = r / a.T, t = r % a.T;
+    bf16x8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = f2bf(L > 0.f ? acc[e] / L : 0.f);
+    *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
+}
+
+// Merge key splits: one block of D threads per (b, kv head, row) - the general form (any head dim, attn_fwd_kernel's partner).
 template <int D>
 __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), Rpad = RT * 16;
@@ -970,7 +1021,6 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
     const int Lk = sdp->s[b].len_after;
     const int ns = min(a.n_splits, ceil_div(Lk, a.split_len));
     const long base = ((long)b * a.Hkv + hk) * a.n_splits;
-    // chunks of 16 splits, all loads of a chunk first, reduction in split order; same arithmetic as attn_combine16_kernel
     float M = -INFINITY, L = 0.f, acc = 0.f;
     for (int s0 = 0; s0 < ns; s0 += 16) {
         float m_[16], l_[16], p_[16];
@@ -982,23 +1032,18 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
                 l_[s] = a.part_ml[prow * 2 + 1];
                 p_[s] = a.part_o[prow * D + d];
             }
-        float Mc = M;
+        float Mc = -INFINITY, Lc = 0.f, accc = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             if (s0 + s < ns) Mc = fmaxf(Mc, m_[s]);
-        if (s0 > 0) {
-            const float sc = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(M - Mc);
-            L *= sc;
-            acc *= sc;
-        }
-        M = Mc;
 #pragma unroll
         for (int s = 0; s < 16; ++s)
             if (s0 + s < ns) {
-                const float w = M == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - M);    // running maxima are kept in the base-2 domain
-                L = __builtin_fmaf(w, l_[s], L);               // explicit FMAs, as in attn_combine16_kernel
-                acc = __builtin_fmaf(w, p_[s], acc);
+                const float w = Mc == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_[s] - Mc);
+                Lc = __builtin_fmaf(w, l_[s], Lc);
+                accc = __builtin_fmaf(w, p_[s], accc);
             }
+        comb_merge(M, L, &acc, 1, Mc, Lc, &accc);
     }
     const int g = r / a.T, t = r % a.T;
     if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(L > 0.f ? acc / L : 0.f);
@@ -1035,7 +1080,9 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
                     attr_set = true;
                 }
                 hipLaunchKernelGGL((attn_lm_kernel<D, 8>), dim3(a.n_splits, a.Hkv * ceil_div(RT, 16), B), dim3(512), LDS, st, a, sd_dev);
-                if (a.n_splits > 1)
+                if (a.n_splits > 16)
+                    hipLaunchKernelGGL((attn_combine16c_kernel<D>), dim3(ceil_div(R, 4), a.Hkv, B), dim3(256), 0, st, a, sd_dev);
+                else if (a.n_splits > 1)
                     hipLaunchKernelGGL((attn_combine16_kernel<D>), dim3(ceil_div(R, 16), a.Hkv, B), dim3(256), 0, st, a, sd_dev);
                 return hipGetLastError();
             }
