@@ -33,6 +33,38 @@ struct GemmTileArgs {
     int wide_epi;               // set by aha_gemm_tile (tuning "tile_epi"): LDS-transposed 16-byte epilogue of the LDS-DMA kernels
 };
 
+// Weight prefetch riders (latency path of the vision tower): extra workgroups of a launch that do nothing but read byte ranges -
+// the weights of GEMMs a few launches ahead - so that those bytes sit in the Infinity Cache when their GEMM starts.
+struct WeightPrefetch {
+    const void* p[4]; long bytes[4];      // byte ranges to pull through the caches (16-byte aligned starts; bytes may be 0)
+    int n_riders;                         // rider workgroups of 256 threads in the launch (0: none)
+};
+#ifdef __HIPCC__
+static __device__ __forceinline__ void prefetch_rider(const WeightPrefetch& pf, const int rider) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    unsigned acc = 0;
+#pragma unroll
+    for (int sgm = 0; sgm < 4; ++sgm) {
+        const long last = pf.bytes[sgm] - 16;                 // clamp instead of branching: every load of a round is issued before any is waited for
+        if (last < 0) continue;
+        const char* base = reinterpret_cast<const char*>(pf.p[sgm]);
+        const long n_pieces = (pf.bytes[sgm] + 4095) >> 12;   // 4-KiB pieces, one 16-byte load per thread, dealt round-robin to the riders
+        for (long pc = rider; pc < n_pieces; pc += (long)pf.n_riders * 16) {
+            u32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                long off = ((pc + (long)j * pf.n_riders) << 12) + (threadIdx.x & 255) * 16;
+                off = off < last ? off : last;
+                v[j] = *reinterpret_cast<const u32x4*>(base + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc ^= v[j][0];
+        }
+    }
+    asm volatile("" ::"v"(acc));                              // the loads stay; nothing is stored
+}
+#endif
+
 struct AttnArgs {
     const bf16* q; long q_bs; int ldq;
     const bf16* k; const bf16* v; long kv_bs; int ldk;     // dense mode only
@@ -46,6 +78,7 @@ struct AttnArgs {
     // LM, frozen-static steps only: Q from the QKV GEMM's split-K slabs (null -> read a.q)
     const float* q_partial; int q_S; long q_slab_stride; int q_ldp;
     const bf16* q_bias; const bf16* rope_cos; const bf16* rope_sin; int n_pos;
+    WeightPrefetch pf;                                     // dense restaging kernel only: riders behind the row workgroups (n_riders = 0: none)
 };
 
 struct ResidNormArgs {
@@ -125,6 +158,8 @@ hipError_t aha_heads(const bf16* xn, int ldx, int row_first, int row_step, int c
 hipError_t aha_im2col_norm(const uint8_t* frames, int N, int S, int P, int Kp, const float* mean3, const float* std3, bf16* out, hipStream_t st);
 hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* pos, bf16* x, int n, int Np, int Dv, hipStream_t st);
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
+hipError_t aha_layernorm_pf(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
+                            const WeightPrefetch* pf, hipStream_t st);   // + weight prefetch riders (latency path); pf may be null
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st);
 hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go, int s, int Dv, int frame_rows, hipStream_t st);

@@ -111,6 +111,9 @@ struct aha_ctx {
     long* gen_pin = nullptr; hipEvent_t gen_ev = nullptr; int gen_cap = 0;
     // operator-level attention (aha_attention_forward): its own descriptor slot ring is the step's (sd_pin / sd_dev)
     int pool_subset = 1;                 // projector only on the patch rows bilinear pooling samples (tuning "pool_subset"; bit-identical)
+    int vit_prefetch_rows = 2400;        // tuning "vit_prefetch": tower encodes of up to this many token rows (4 frames of 576) prefetch weights from their LayerNorm launches
+    int vit_riders = 256;                // tuning "vit_riders": rider workgroups per prefetching launch
+    int vit_alias = 0;                   // diagnostic: encoder layer l runs layer l % vit_alias's weights (0 = its own): a tower whose weights stay cache-resident
     int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)

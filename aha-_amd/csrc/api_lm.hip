@@ -320,9 +320,9 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             }
             // o_proj -> slabs ; reduce + residual + post-attention RMSNorm
             const int So = pick_split(c, GK_O, w.o, M, 1);
-            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
             ResidNormArgs ra;
             memset(&ra, 0, sizeof(ra));
+            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
             ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
             ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
             const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);

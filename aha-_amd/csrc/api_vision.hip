@@ -9,6 +9,7 @@ hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ldw, int 
     GemmTileArgs g;
     g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
     g.residual = residual; g.ldr = ldr; g.rowadd = rowadd; g.rowadd_period = period > 0 ? period : 1; g.ldra = ldra;
+    g.wide_epi = 0;
     return aha_gemm_tile(&g, st);
 }
 
@@ -37,9 +38,25 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
     const bool clip = d.v_kind == AHA_VISION_CLIP;
     const int Dv = d.v_hidden, T = c->Tt, rows = n * T, vhd = Dv / d.v_heads;
     const int act = clip ? ACT_QUICK_GELU : ACT_GELU_TANH;
+    // Latency path (a few frames): the tower's kernels are latency-bound chains with HBM almost idle (25 MB of weights per ~80 us layer), and
+    // every GEMM starts by waiting for its first weight tiles from HBM.  The attention launch of a layer (144 workgroups for ~12 us at one
+    // frame: most of the chip idle) therefore carries RIDERS - extra workgroups that only read bytes (prefetch_rider, aha_kernels.h) - for
+    // the weights used from two launches on: this layer's fc1 and fc2, the next layer's QKV and out-proj (after the last layer: the
+    // projector's two matrices, used by the encode calls right after the tower).  The first layer's QKV and out-proj weights ride on its
+    // LN1 launch.  With the weights in the Infinity Cache the one-frame encode measures 2.09 -> 1.9 ms (tools/diag/vit_prefetch.py; fully
+    // cache-resident weights, tuning "vit_alias": 1.74).  Riders change no output bit.  Tuning "vit_prefetch" = rows up to which it is on
+    // (0: off); the throughput path never prefetches (its GEMMs are not latency-bound and the riders would only take CUs).
+    const bool pf = rows <= c->vit_prefetch_rows && c->vit_riders > 0;
+    const size_t b_qkv = (size_t)3 * Dv * Dv * 2, b_o = (size_t)Dv * Dv * 2, b_1 = (size_t)d.v_inter * Dv * 2, b_2 = (size_t)Dv * c->Fp * 2;
     for (int l = l0; l < l1; ++l) {
-        const VLayerW& w = c->V[l];
-        HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+        const auto vw = [&](int i) -> const VLayerW& { return c->V[c->vit_alias > 0 ? i % c->vit_alias : i]; };
+        const VLayerW& w = vw(l);
+        const bool last = l + 1 >= d.v_layers;
+        if (pf && l == l0) {
+            WeightPrefetch p0{{w.wqkv, w.wo, nullptr, nullptr}, {(long)b_qkv, (long)b_o, 0, 0}, c->vit_riders};
+            HIPCHK(c, aha_layernorm_pf(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, &p0, st));
+        } else
+            HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
         HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
         AttnArgs a;
         memset(&a, 0, sizeof(a));
@@ -49,6 +66,18 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
         a.T = T; a.G = 1; a.Hkv = d.v_heads; a.Lk = T;
         a.split_len = round_up(T, 64); a.n_splits = 1;
         a.scale = 1.0f / sqrtf((float)vhd);
+        if (pf) {
+            a.pf.p[0] = w.w1; a.pf.bytes[0] = (long)b_1;
+            a.pf.p[1] = w.w2; a.pf.bytes[1] = (long)b_2;
+            if (!last) {
+                a.pf.p[2] = vw(l + 1).wqkv; a.pf.bytes[2] = (long)b_qkv;
+                a.pf.p[3] = vw(l + 1).wo; a.pf.bytes[3] = (long)b_o;
+            } else if (c->p0w && c->p2w) {
+                a.pf.p[2] = c->p0w; a.pf.bytes[2] = (long)d.hidden * Dv * 2;
+                a.pf.p[3] = c->p2w; a.pf.bytes[3] = (long)d.hidden * d.hidden * 2;
+            }
+            a.pf.n_riders = c->vit_riders;
+        }
         HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
         HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
         HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));

@@ -479,6 +479,13 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
     using C = AttnCfg<D>;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
+    // weight-prefetch riders (latency path, aha_kernels.h): the last a.pf.n_riders rows of grid.y of frame 0 only read bytes; with a
+    // single frame this launch covers 144 of the 256 CUs for ~12 us, so the riders run beside it for free
+    const int ny = (int)gridDim.y - a.pf.n_riders;
+    if ((int)blockIdx.y >= ny) {
+        if (blockIdx.z == 0) prefetch_rider(a.pf, (int)blockIdx.y - ny);
+        return;
+    }
     attn_dense_body<D, TPW>(a, blockIdx.y, blockIdx.z, Ks, Vs);
 }
 // Background tower (tuning "tower_bg", see gemm_tile_bg_kernel): the same body, PERSISTENT - at most one workgroup per CU (the
@@ -1061,7 +1068,10 @@ static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-s
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
 template <int D>
-static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, hipStream_t st) {
+static hipError_t launch_attn(const AttnArgs& a_in, const StepDesc* sd_dev, int B, hipStream_t st) {
+    AttnArgs a = a_in;
+    const int riders = a.pf.n_riders > 0 && !sd_dev ? a.pf.n_riders : 0;      // weight-prefetch riders: dense restaging kernel, one tile per wave, only
+    a.pf.n_riders = 0;
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
     dim3 grid(a.n_splits, a.Hkv * RG, B);
     if (sd_dev) {
@@ -1137,7 +1147,10 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
             dim3 g(1, a.Hkv * ceil_div(RT, 8), B);
             hipLaunchKernelGGL((attn_dense_kernel<D, D <= 64 ? 2 : 1>), g, dim3(256), 0, st, a);
         } else {
-            hipLaunchKernelGGL((attn_dense_kernel<D, 1>), grid, dim3(256), 0, st, a);
+            // the one dense launch that honours weight-prefetch riders (aha_attention zeroes them for every other kernel)
+            AttnArgs ar = a;
+            ar.pf.n_riders = riders;
+            hipLaunchKernelGGL((attn_dense_kernel<D, 1>), dim3(grid.x, grid.y + riders, grid.z), dim3(256), 0, st, ar);
         }
     }
     return hipGetLastError();
@@ -1153,7 +1166,8 @@ extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int 
     AttnArgs a = *a_;
     a.hd = head_dim;
     if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
-    if (!sd && head_dim <= 96 && g_attn_d96 && !g_attn_bg) {       // tower_bg: the 128-wide template below has the background form (same bits)
+    if (!sd && head_dim <= 96 && g_attn_d96 && !g_attn_bg) {
+        a.pf.n_riders = 0;       // tower_bg: the 128-wide template below has the background form (same bits)
         // dense heads of 65..96 channels (so400m: 72): 3 QK^T k-steps and 6 output tiles instead of the 128-wide template's 4 and 8.
         // The padded channels are exact zeros in both templates, so a row's bits do not depend on which one ran.
         // Measured at 32 frames x 729 keys x 16 heads of 72: 279 -> 243 us per layer; two query tiles per wave: 306 us (worse).

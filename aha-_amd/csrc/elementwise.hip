@@ -521,11 +521,22 @@ __global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, in
 // LayerNorm over the last dim, one wave per row (4 rows per block); D % 8 == 0, D <= 4096.  NC = 16-byte chunks per lane the
 // instantiation holds (ceil(D / 512) <= NC): the 8-chunk form needs 132 VGPRs (3 waves per SIMD, two loads in flight per wave
 // at D = 1024: 3.8 TB/s on the 32-frame tower); the 2- and 3-chunk forms run at full occupancy.  Same per-lane order: same bits.
-template <int NC>
+//
+// Latency path (one to four frames): the launch can carry RIDERS - extra workgroups in front of the row workgroups that do nothing
+// but read byte ranges (the weights of GEMMs a few launches ahead, WeightPrefetch in aha_kernels.h) so that those bytes sit in the
+// Infinity Cache when their GEMM starts.  At one frame the tower's kernels are latency-bound chains with HBM almost idle (25 MB
+// of weights per 85 us layer): with the weights cache-resident the encode measures 1.74 ms instead of 2.09 (tuning "vit_alias",
+// tools/diag/vit_alias.py).  Riders change no output bit; with n_riders = 0 the launch is the plain LayerNorm.
+template <int NC, bool PF = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
                                                         const bf16* __restrict__ bias, bf16* __restrict__ out, int ldo,
-                                                        int M, int D, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                        int M, int D, float eps, WeightPrefetch pf) {
+    int blk = blockIdx.x;
+    if constexpr (PF) {
+        if (blk < pf.n_riders) { prefetch_rider(pf, blk); return; }
+        blk -= pf.n_riders;
+    }
+    const int row = blk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nch = D >> 3;
     bf16x8 v[NC];
@@ -819,11 +830,33 @@ hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* p
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
                          hipStream_t st) {
     if ((D & 7) || D > 4096) return hipErrorInvalidValue;
+    return aha_layernorm_pf(x, ldx, w, b, out, ldo, M, D, eps, nullptr, st);
+}
+// LayerNorm whose launch also pulls the byte ranges of *pf_ through the caches (riders in front of the row workgroups)
+hipError_t aha_layernorm_pf(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
+                            const WeightPrefetch* pf_, hipStream_t st) {
+    if ((D & 7) || D > 4096) return hipErrorInvalidValue;
     const int nc = ceil_div(D >> 3, 64);
-    const dim3 grid(ceil_div(M, 4)), blk(256);
-    if (nc <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
-    else if (nc <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
-    else hipLaunchKernelGGL(layernorm_kernel<8>, grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps);
+    WeightPrefetch pf{};
+    if (pf_) pf = *pf_;
+    long total = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!pf.p[i] || pf.bytes[i] < 16) { pf.p[i] = nullptr; pf.bytes[i] = 0; }
+        if ((uintptr_t)pf.p[i] & 15) return hipErrorInvalidValue;
+        total += pf.bytes[i];
+    }
+    const bool on = pf.n_riders > 0 && total > 0;
+    if (!on) pf.n_riders = 0;
+    const dim3 grid(ceil_div(M, 4) + pf.n_riders), blk(256);
+    if (on) {
+        if (nc <= 2) hipLaunchKernelGGL((layernorm_kernel<2, true>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+        else if (nc <= 3) hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+        else hipLaunchKernelGGL((layernorm_kernel<8, true>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+    } else {
+        if (nc <= 2) hipLaunchKernelGGL((layernorm_kernel<2>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+        else if (nc <= 3) hipLaunchKernelGGL((layernorm_kernel<3>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+        else hipLaunchKernelGGL((layernorm_kernel<8>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
+    }
     return hipGetLastError();
 }
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st) {

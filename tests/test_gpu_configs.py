@@ -535,11 +535,20 @@ def test_bench_launches_ranks_itself_and_the_rccl_path_runs():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "tools", "abi_allgather_check.py")],
-                       capture_output=True, text=True, timeout=400, env=env)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-    chk = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"ok"')][-1])
+    # the launcher and its rank(s) run in a process group of their own: if the 400 s backstop ever fires (every rank also carries its own
+    # 180 s deadline that works inside C calls), the WHOLE group is killed - no rank is left holding the GPU - and nothing is retried
+    import signal
+    p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "tools", "abi_allgather_check.py")],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        so, se = p.communicate(timeout=400)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        so, se = p.communicate()
+        raise AssertionError(("abi_allgather_check timed out; process group killed", so[-2000:], se[-3000:]))
+    assert p.returncode == 0, (so[-2000:], se[-3000:])
+    chk = json.loads([ln for ln in so.splitlines() if ln.startswith('{"ok"')][-1])
     assert chk["ok"] is True and chk["ranks"] == 1 and chk["allgather_us"] > 0, chk
 
 

@@ -3,8 +3,10 @@
 from a unique id inside libaha_amd.so, include/aha_amd.h "collective") against torch.distributed's all_gather of the same rows.
 
 A separate PROCESS GROUP on purpose: a collective that stalls must surface as this program's non-zero exit,
-never inside bench.py.  Every rank arms a hard deadline (SIGALRM -> exit 3 after printing which step it was in); nothing is
-retried.
+never inside bench.py.  Every rank arms a hard deadline that fires while the main thread is blocked INSIDE a C call (RCCL init,
+hipStreamSynchronize, a barrier): a daemon watchdog thread - ctypes and torch release the GIL around those calls - names the step
+the rank stalled in on stderr and ends the process with os._exit(3).  (A Python signal handler cannot do this: CPython runs
+handlers only between bytecodes of the main thread, so SIGALRM is never served while that thread sits in C.)  Nothing is retried.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/abi_allgather_check.py
     python tools/abi_allgather_check.py            # one rank, sets up its own rendezvous
@@ -14,8 +16,8 @@ Rank 0 prints ONE JSON line {"ok": true, "ranks": N, "allgather_us": ...}; exit 
 import ctypes as C
 import json
 import os
-import signal
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,16 +26,26 @@ sys.path.insert(0, ROOT)
 STEP = ["start"]
 
 
-def _deadline(signum, frame):
-    sys.stderr.write(f"abi_allgather_check: rank {os.environ.get('RANK', '0')} stalled in step '{STEP[0]}'\n")
-    sys.stderr.flush()
-    os._exit(3)
+def arm_deadline(seconds, step=STEP, what="abi_allgather_check"):
+    """Hard deadline for a process whose main thread may block inside C: after `seconds` a daemon thread writes the step the
+    process is in to stderr (os.write: no locks shared with the blocked thread) and ends it with exit code 3.  Returns a
+    callable that disarms it.  tests/test_host_logic.py exercises it against a main thread blocked in libc sleep()."""
+    done = threading.Event()
+
+    def _watch():
+        if done.wait(seconds):
+            return
+        try:
+            os.write(2, f"{what}: rank {os.environ.get('RANK', '0')} stalled in step '{step[0]}' ({seconds} s deadline)\n".encode())
+        finally:
+            os._exit(3)
+    threading.Thread(target=_watch, name="deadline", daemon=True).start()
+    return done.set
 
 
 def main():
     rows = int(os.environ.get("AHA_CHECK_ROWS", "256"))
-    signal.signal(signal.SIGALRM, _deadline)
-    signal.alarm(int(os.environ.get("AHA_CHECK_DEADLINE_S", "180")))
+    disarm = arm_deadline(float(os.environ.get("AHA_CHECK_DEADLINE_S", "180")))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
     os.environ.setdefault("RANK", "0")
@@ -99,7 +111,7 @@ def main():
     all_ok = bool(flag.item())
     if rank == 0:
         print(json.dumps({"ok": all_ok, "ranks": world, "rows_per_rank": rows, "bytes_per_rank": rows * 12, "allgather_us": us}), flush=True)
-    signal.alarm(0)
+    disarm()
     sys.exit(0 if all_ok else 1)
 
 

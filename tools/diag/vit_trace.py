@@ -13,6 +13,12 @@ cfg = preset(sys.argv[2] if len(sys.argv) > 2 else "bench")
 w = make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True)
 rt = Runtime(cfg, w, max_step_tokens=64, max_vit_frames=n)
 fr = make_frames(n, cfg.vision.image_size, seed=1).cuda()
-for _ in range(10): rt.visual_embed(fr)
+if os.environ.get("AHA_VIT_PREFETCH") is not None:
+    rt.set_tuning("vit_prefetch", int(os.environ["AHA_VIT_PREFETCH"]))
+junk = torch.empty(1 << 29, dtype=torch.uint8, device="cuda") if n <= 4 else None      # latency path: flush the caches between encodes as an LM step would
+for _ in range(10):
+    if junk is not None:
+        junk.add_(1); torch.cuda.synchronize()
+    rt.visual_embed(fr)
 torch.cuda.synchronize()
 rt.close()

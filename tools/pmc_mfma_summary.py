@@ -29,6 +29,8 @@ for (name, grid, wg), c in acc.items():
             row["wave_parked_frac"] = round(m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"], 3)
             row["issue_stall_frac"] = round(m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"], 3)
     rows.append(row)
+if not rows:
+    sys.exit(f"pmc_mfma_summary: no counter rows under {sys.argv[1]} - nothing written to {sys.argv[2]} (a claimed measurement needs its table)")
 rows.sort(key=lambda r: -r.get("GRBM_GUI_ACTIVE", 0) * r["dispatches"])
 json.dump({"formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); *_frac relative to SQ_WAVE_CYCLES",
            "kernels": rows[:16]}, open(sys.argv[2], "w"), indent=1)
