@@ -90,17 +90,6 @@ struct ResidNormArgs {
     int xkb;                         // 0: xn row-major [M][ldx]; else k-blocked [H/32][xkb rows][32] (consumer: the mid-M GEMM)
 };
 
-// fused MLP block (lm_fused.hip): resid_norm -> gate/up + SwiGLU -> down, one launch, two grid barriers
-struct MlpBlockArgs {
-    ResidNormArgs rn; int M;
-    GemmWsArgs gu; int gu_blocks;                 // gate/up: virtual workgroups (8 waves x 2 n-tiles each), S = 1
-    GemmWsArgs dn; int dn_blocks_x;               // down: virtual grid (dn_blocks_x, dn.S)
-    unsigned long long* ctr; unsigned long long base;   // arrival counters ([0] top, [16*(1+g)] group g) and the top value before this launch
-    int per_group;                                // workgroups per arrival group (0: flat counter)
-    int sc1;                                      // 1: xn / act stored write-through, barriers without release fences
-    int* err;                                     // set to 1 if a barrier wait timed out
-};
-
 // frame ingest (ingest.hip): one source frame -> one [3,S,S] canvas
 struct IngestArgs {
     const uint8_t* src; int h, w, src_bgr;       // uint8 [h][w][3]; src_bgr: channels arrive B,G,R
@@ -140,9 +129,6 @@ void aha_attention_set_dense_tpw(int v);
 void aha_attention_set_lm_kernel(int v);
 void aha_attention_set_head_kernel(int v);
 void aha_attention_set_d96(int v);
-void aha_attention_set_bg(int v);
-void aha_gemm_tile_set_bg(int on);
-void aha_gemm_tile_set_bg_cus(int n);
 extern "C" void aha_gemm_wl_set_balanced(int on);
 hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd_dev, int B, int head_dim, hipStream_t st);   // sd_dev: DEVICE pointer or null (dense)
 hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st);
@@ -166,6 +152,4 @@ hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go,
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);
 hipError_t aha_ingest_launch(const IngestArgs* a, int method, hipStream_t st);
-hipError_t aha_lm_mlp_block(MlpBlockArgs* p, int grid, hipStream_t st);
-int aha_lm_mlp_block_counter_step(int grid);
 }

@@ -66,9 +66,9 @@ extern "C" int aha_ctx_create(const aha_model_desc* d, int device, aha_ctx** out
     // ---- graph replay state
     if ((rc = dalloc(c, &c->graph_scores, (size_t)AHA_MAX_B * 3))) return rc;
     if (hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) return fail(c, AHA_E_HIP, "hipStreamCreate failed");
-    // ---- fused-kernel barrier state
-    if ((rc = dalloc(c, &c->bar_ctr, 16 * 17)) || (rc = dalloc(c, &c->bar_err, 1))) return rc;
-    if (hipMemset(c->bar_ctr, 0, 16 * 17 * sizeof(unsigned long long)) != hipSuccess || hipMemset(c->bar_err, 0, sizeof(int)) != hipSuccess)
+    // ---- device error flag
+    if ((rc = dalloc(c, &c->bar_err, 1))) return rc;
+    if (hipMemset(c->bar_err, 0, sizeof(int)) != hipSuccess)
         return fail(c, AHA_E_NOMEM, "hipMemset failed");
     {
         hipDeviceProp_t prop;
@@ -143,13 +143,10 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "vit_riders") c->vit_riders = value < 0 ? 0 : (value > 1024 ? 1024 : value);   // rider workgroups per prefetching launch
     else if (k == "vit_alias") c->vit_alias = value;              // diagnostic (tools/diag/vit_alias.py): wrong embeddings on purpose
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
-    else if (k == "fuse_mlp") c->fuse_mlp = value;               // 1: resid_norm + gate/up + down in one launch (M <= 64); 2: sc1 hand-offs
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_lm") aha_attention_set_lm_kernel(value);   // 1 (default): frame-sized LM steps use attn_lm_kernel (LDS-DMA, all row tiles per workgroup)
     else if (k == "attn_head") aha_attention_set_head_kernel(value);   // whole-head-in-LDS dense (ViT) attention: 0 off, 1 auto, 2 always when eligible
     else if (k == "attn_d96") aha_attention_set_d96(value);             // 96-wide dense attention template for head dims 65..96: 0 pads to 128
-    else if (k == "tower_bg") { aha_gemm_tile_set_bg(value); aha_attention_set_bg(value); }   // background tower: one four-wave workgroup per CU, room left for LM workgroups (bench.py --overlap)
-    else if (k == "bg_cus") aha_gemm_tile_set_bg_cus(value);      // workgroups of the background tower GEMM (default 256: one per CU)
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
     else if (k == "tile_p288s") aha_gemm_tile_p288_set_pipelined(value);   // 1 (default): software-pipelined fragment reads in the persistent tile kernel

@@ -80,8 +80,8 @@ struct aha_ctx {
     hipStream_t cap_stream = nullptr;
     float* graph_scores = nullptr;
     int use_graph = 1, tune_epoch = 0;
-    // fused MLP block (lm_fused.hip): device arrival counter + its host-side base, error flag, switch
-    unsigned long long* bar_ctr = nullptr; unsigned long long bar_base = 0; int* bar_err = nullptr; int fuse_mlp = 0, n_cus = 0;
+    int* bar_err = nullptr;                                  // device error flag the heads kernel checks (poisons the scores with NaN when set)
+    int n_cus = 0;
     struct IngestTab { int *xb = nullptr, *xk = nullptr, *yb = nullptr, *yk = nullptr; int xks = 0, yks = 0;
                        hipStream_t up_stream = nullptr; hipEvent_t ready = nullptr; };   // tables are uploaded on up_stream; other streams wait on `ready`
     std::vector<void*> pinned;                               // host staging of coefficient tables (kept: async uploads read them)

@@ -17,6 +17,7 @@
 // Online softmax in fp32; P rounded to bf16 before PV (flash/sdpa semantics).  With more than
 // one key split the kernel writes (m, l, unnormalised O) partials and attn_combine merges them.
 #include "aha_kernels.h"
+#include <type_traits>
 
 
 template <int D> struct AttnCfg {
@@ -386,6 +387,7 @@ static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const 
         // AGPR moves per block).
         bf16x8 pb[TPW][2];
         const bool tail = jb + 64 > j1;                              // uniform
+        const int lim = j1 - jb - 4 * q4;                            // key kt*16 + e of this lane's quad exists iff kt*16 + e < lim
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             f32x4 s[4];
@@ -404,7 +406,7 @@ static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const 
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (jb + kt * 16 + 4 * q4 + e >= j1) s[kt][e] = -INFINITY;
+                        if (kt * 16 + e >= lim) s[kt][e] = -INFINITY;
             }
             float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -412,22 +414,20 @@ static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const 
             bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
             bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
             const float m_new = fmaxf(m_run[tt], bmax * c2);         // -inf * c2 = -inf
-            float alpha = 1.f, psum = 0.f;
-            if (m_new == -INFINITY) {
-                pb[tt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                pb[tt][1] = pb[tt][0];
-            } else {
-                alpha = __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf -> 0
-                const float nm = -m_new;
+            // a row that has seen no key yet (m_new = -inf: only while every key so far was masked) takes alpha = 1 and the offset 0, so
+            // that its probabilities are 2^(-inf) = 0 without a branch (the branch cost eleven register presets per tile in every block)
+            const bool unseen = m_new == -INFINITY;
+            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf, m_new finite -> 0
+            const float nm = unseen ? 0.f : -m_new;
+            float psum = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
-                        psum += p;
-                        pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
-                    }
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
+                    psum += p;
+                    pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                }
             m_run[tt] = m_new;
             l_run[tt] = l_run[tt] * alpha + psum;
 #pragma unroll
@@ -475,7 +475,7 @@ static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const 
 }
 
 template <int D, int TPW>
-__global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (TPW == 1 && D <= 64) ? 4 : 1) void attn_dense_kernel(AttnArgs a) {      // D = 64: four workgroups per CU (<= 128 VGPRs)
     using C = AttnCfg<D>;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
@@ -488,19 +488,6 @@ __global__ __launch_bounds__(256) void attn_dense_kernel(AttnArgs a) {
     }
     attn_dense_body<D, TPW>(a, blockIdx.y, blockIdx.z, Ks, Vs);
 }
-// Background tower (tuning "tower_bg", see gemm_tile_bg_kernel): the same body, PERSISTENT - at most one workgroup per CU (the
-// launch pads its LDS request so that two do not fit) walks the (KV head x row group, frame) items; identical arithmetic per row.
-template <int D>
-__global__ __launch_bounds__(256, D <= 64 ? 4 : 2) void attn_dense_bg_kernel(AttnArgs a, int ny, int items) {
-    using C = AttnCfg<D>;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
-    for (int it = blockIdx.x; it < items; it += gridDim.x) {
-        attn_dense_body<D, 1>(a, it % ny, it / ny, Ks, Vs);
-        __syncthreads();                                             // every wave is done with this item's K/V image
-    }
-}
-
 // Butterfly steps over lanes l ^ 16 and l ^ 32 on the vector ALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of
 // ds_bpermute round trips through the LDS: swap(x, x) leaves [r0 r0 r2 r2] / [r1 r1 r3 r3] (16-lane rows) resp. [lo lo] / [hi hi]
 // (32-lane halves) in the two results, so one max / add of the pair is the xor-16 / xor-32 reduction step in every lane.  max is
@@ -609,9 +596,14 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    for (int jb = 0; jb < j1; jb += 64) {
+    // One 64-key block for the wave's TPW tiles.  TAIL (only the last block of a key count that is not a multiple of 64) masks the keys
+    // past the end and handles rows that have seen no key yet; the full-block form has neither: every score is finite, so m_new is, and
+    // the 16 key-index compares, the masked-row branch and its register presets (~60 vector instructions per tile that the one-loop
+    // form executed or set up in EVERY block) are gone.  Same operations in the same order on every value: same bits as before and as
+    // attn_dense_kernel.
+    auto block = [&](const int jb, auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         bf16x8 pb[TPW][2];
-        const bool tail = jb + 64 > j1;                              // uniform
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
             f32x4 s[4];
@@ -621,16 +613,17 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
                 const int row = jb + kt * 16 + r16;
 #pragma unroll
                 for (int ks = 0; ks < C::KSQ; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (row & 7)) << 3)]);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[row * D + (((ks * 4 + q4) ^ (r16 & 7)) << 3)]);   // row & 7 == r16 & 7
                     s[kt] = mfma16(kf, qf[tt][ks], s[kt]);
                 }
             }
-            if (tail) {
+            if constexpr (TAIL) {
+                const int lim = j1 - jb - 4 * q4;                    // key kt*16 + e of this lane's quad exists iff kt*16 + e < lim
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (jb + kt * 16 + 4 * q4 + e >= j1) s[kt][e] = -INFINITY;
+                        if (kt * 16 + e >= lim) s[kt][e] = -INFINITY;
             }
             float bmax = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -638,43 +631,45 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
             bmax = xor16_max(bmax);                                  // lanes l, l^16, l^32, l^48 hold one query row's keys
             bmax = xor32_max(bmax);
             const float m_new = fmaxf(m_run[tt], bmax * c2);         // -inf * c2 = -inf
-            float alpha = 1.f, psum = 0.f;
-            if (m_new == -INFINITY) {
-                pb[tt][0] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                pb[tt][1] = pb[tt][0];
-            } else {
-                alpha = __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf -> 0
-                const float nm = -m_new;
+            // a row that has seen no key yet (m_new = -inf: only while every key so far was masked) takes alpha = 1 and the offset 0, so
+            // that its probabilities are 2^(-inf) = 0 without a branch (the branch cost eleven register presets per tile in every block)
+            const bool unseen = TAIL && m_new == -INFINITY;
+            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf, m_new finite -> 0
+            const float nm = unseen ? 0.f : -m_new;
+            float psum = 0.f;
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
-                        psum += p;
-                        pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
-                    }
-            }
+                for (int e = 0; e < 4; ++e) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][e], c2, nm));   // masked: 2^-inf = 0
+                    psum += p;
+                    pb[tt][kt >> 1][(kt & 1) * 4 + e] = f2bf(p);
+                }
             m_run[tt] = m_new;
             l_run[tt] = l_run[tt] * alpha + psum;
 #pragma unroll
             for (int i = 0; i < C::DT; ++i) o[tt][i] *= alpha;
             if (TPW > 1) __builtin_amdgcn_sched_barrier(0);          // keep the tiles sequential (hipcc would re-merge them)
         }
-        // ---- O^T += V^T P^T: one transposed V fragment feeds TPW MFMAs
+        // ---- O^T += V^T P^T: one transposed V fragment feeds TPW MFMAs.  (r >> 1) & 3 of a V row r = jb + 32 kp (+16) + vrow is that of vrow.
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const int r0 = jb + (2 * kp) * 16 + vrow, r1 = r0 + 16;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4)(&Vs[r0 * D + (((2 * dt + (vcol >> 3)) ^ (2 * ((r0 >> 1) & 3))) << 3) + (vcol & 7)]));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (lds_s16x4)(&Vs[r1 * D + (((2 * dt + (vcol >> 3)) ^ (2 * ((r1 >> 1) & 3))) << 3) + (vcol & 7)]));
+                const int vsl = (((2 * dt + (vcol >> 3)) ^ (2 * ((vrow >> 1) & 3))) << 3) + (vcol & 7);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Vs[r0 * D + vsl]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Vs[r1 * D + vsl]));
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt) o[tt][dt] = mfma16(vf, pb[tt][kp], o[tt][dt]);
             }
         }
+    };
+    {
+        int jb = 0;
+        for (; jb + 64 <= j1; jb += 64) block(jb, std::false_type{});
+        if (jb < j1) block(jb, std::true_type{});
     }
     if (!wave_on) return;
 #pragma unroll
@@ -1062,8 +1057,6 @@ static int g_attn_head = 1;      // tuning "attn_head": whole-head-in-LDS dense 
 extern "C" void aha_attention_set_head_kernel(int v) { g_attn_head = v; }
 static int g_attn_d96 = 1;       // tuning "attn_d96": 96-wide dense template for head dims 65..96 (so400m's 72): 0 = pad to 128 as round 2
 extern "C" void aha_attention_set_d96(int v) { g_attn_d96 = v; }
-static int g_attn_bg = 0;        // tuning "tower_bg": dense attention as ONE four-wave workgroup per CU (LDS padded to 88 KB), see gemm_tile.hip
-extern "C" void aha_attention_set_bg(int v) { g_attn_bg = v; }
 static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-sized steps (> 64 rows per KV head, head_dim 128): 0 never, 1 auto, 2 always
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
@@ -1108,19 +1101,6 @@ static hipError_t launch_attn(const AttnArgs& a_in, const StepDesc* sd_dev, int 
         // packed fp32 ops and skipping idle rescales did not move it either (profiles/r02_vit_batch.txt): the per-block chain
         // barrier -> fragment reads -> MFMA -> softmax -> MFMA runs with little overlap at ~108 us.  Default: one tile per wave, the
         // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
-        if (g_attn_bg) {
-            // background tower: the restaging kernel's body, persistent, capped at one workgroup per CU by an unused dynamic LDS request
-            constexpr int PAD = 70 * 1024;
-            static bool bg_attr = false;
-            if (!bg_attr) {
-                hipError_t e = hipFuncSetAttribute((const void*)attn_dense_bg_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, PAD);
-                if (e != hipSuccess) return e;
-                bg_attr = true;
-            }
-            const int ny = a.Hkv * RG, items = ny * B;
-            hipLaunchKernelGGL((attn_dense_bg_kernel<D>), dim3(items < 256 ? items : 256), dim3(256), PAD, st, a, ny, items);
-            return hipGetLastError();
-        }
         if constexpr (D == 64) {
             // whole head LDS-resident (attn_head64_kernel): 64-wide heads whose K + V fit the CU's LDS and whose query rows fit
             // 12 waves x 3 tiles; needs enough (frame, head) pairs to give every CU a workgroup (single-frame latency stays
@@ -1166,8 +1146,8 @@ extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int 
     AttnArgs a = *a_;
     a.hd = head_dim;
     if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
-    if (!sd && head_dim <= 96 && g_attn_d96 && !g_attn_bg) {
-        a.pf.n_riders = 0;       // tower_bg: the 128-wide template below has the background form (same bits)
+    if (!sd && head_dim <= 96 && g_attn_d96) {
+        a.pf.n_riders = 0;
         // dense heads of 65..96 channels (so400m: 72): 3 QK^T k-steps and 6 output tiles instead of the 128-wide template's 4 and 8.
         // The padded channels are exact zeros in both templates, so a row's bits do not depend on which one ran.
         // Measured at 32 frames x 729 keys x 16 heads of 72: 279 -> 243 us per layer; two query tiles per wave: 306 us (worse).

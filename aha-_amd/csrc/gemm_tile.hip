@@ -470,122 +470,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINB) void gemm_tile_dma_ke
 }
 
 // ---------------------------------------------------------------------------------------------
-// BACKGROUND tower GEMM (tuning "tower_bg"; bench.py --overlap): 128x128 tiles, FOUR waves (one per SIMD, <= 128 VGPRs), three
-// 32 KB LDS-DMA stages (96 KB: one workgroup per CU), PERSISTENT: at most one workgroup per CU is launched and walks its tiles,
-// so the whole grid is resident from the start.  That is the point: a kernel with workgroups still waiting for a slot keeps the
-// workgroup dispatcher busy, and kernels of another queue (the LM step's ~200 short launches) then start only at its tail
-// (measured: 52 us of queueing per LM launch underneath the non-persistent form of this kernel).  With the grid resident and
-// 384 VGPRs per SIMD + 64 KB of LDS left on every CU, any LM workgroup is placed at once.  Same k order as every tile variant.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void gemm_tile_bg_kernel(GemmTileArgs g) {
-    constexpr int WI = 4, WJ = 4, WAVES_N = 2, STAGES = 3;
-    constexpr int BM = 128, BN = 128, NT = 256;
-    constexpr int ROWS = BM + BN, STAGE = ROWS * TBK;
-    constexpr int P = ROWS * 8 / NT;                                // 8 DMA pieces per thread per stage
-    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
-    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, r16 = lane & 15;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int tiles_n = ceil_div(g.N, BN), tiles_m = ceil_div(g.M, BM);
-    const int nblk = tiles_n * tiles_m;
-    const int nk = g.K / TBK;
-    const bool wide = tile_epilogue_wide_ok(g);
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-
-    for (int tile = blockIdx.x; tile < nblk; tile += gridDim.x) {
-        constexpr int GROUP_M = 8;
-        const int per_group = GROUP_M * tiles_n, grp = tile / per_group, first_m = grp * GROUP_M;
-        const int gmn = min(tiles_m - first_m, GROUP_M), inner = tile % per_group;
-        const int m0 = (first_m + inner % gmn) * BM, n0 = (inner / gmn) * BN;
-
-        f32x4 acc[WI][WJ];
-#pragma unroll
-        for (int i = 0; i < WI; ++i)
-#pragma unroll
-            for (int j = 0; j < WJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const bf16* src[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int c = i * NT + tid, row = c >> 3, ch = (c & 7) ^ (row & 7);
-            src[i] = row < BM ? g.A + min(m0 + row, g.M - 1) * g.lda + ch * 8
-                              : g.W + min(n0 + row - BM, g.N - 1) * g.ldw + ch * 8;
-        }
-        auto dma = [&](int kt, int stage) {
-            const int k0 = min(kt, nk - 1) * TBK;
-            bf16* sa = lds + stage * STAGE;
-#pragma unroll
-            for (int i = 0; i < P; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + k0), (lptr_t)(sa + (i * NT + wave * 64) * 8), 16, 0, 0);
-        };
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s) dma(s, s);
-        int st_cur = 0, st_new = STAGES - 1;
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * P) : "memory");
-            __builtin_amdgcn_s_barrier();
-            dma(kt + STAGES - 1, st_new);
-            const bf16* sa = lds + st_cur * STAGE;
-            const bf16* sb = sa + BM * TBK;
-#pragma unroll
-            for (int ks = 0; ks < TBK / 32; ++ks) {
-                bf16x8 af[WI], wf[WJ];
-#pragma unroll
-                for (int i = 0; i < WI; ++i) {
-                    const int row = wm * (16 * WI) + i * 16 + r16;
-                    af[i] = *reinterpret_cast<const bf16x8*>(&sa[row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
-                }
-#pragma unroll
-                for (int j = 0; j < WJ; ++j) {
-                    const int wrow = wn * (16 * WJ) + j * 16 + r16;
-                    wf[j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * TBK + (((ks * 4 + q) ^ (wrow & 7)) << 3)]);
-                }
-#pragma unroll
-                for (int i = 0; i < WI; ++i)
-#pragma unroll
-                    for (int j = 0; j < WJ; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            }
-            st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
-            st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the dead refills too: the stages become epilogue staging
-        __builtin_amdgcn_s_barrier();                              // every wave is done reading the stages
-        if (wide) {
-            tile_epilogue_lds<WI, WJ>(g, acc, lds + wave * (16 * WI * (16 * WJ + 8)), m0 + wm * (16 * WI), n0 + wn * (16 * WJ), lane);
-        } else {
-            const bf16x4 z4 = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < WI; ++i) {
-                const int m = m0 + wm * (16 * WI) + i * 16 + r16;
-                const int mc = min(m, g.M - 1);
-#pragma unroll
-                for (int j = 0; j < WJ; ++j) {
-                    const int n = n0 + wn * (16 * WJ) + j * 16 + q * 4, nc = min(n, g.N - 4);
-                    const bf16x4 bv = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + nc) : z4;
-                    const bf16x4 rv = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + nc) : z4;
-                    const bf16x4 pv = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + nc) : z4;
-                    if (m >= g.M || n >= g.N) continue;
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = rbf(acc[i][j][e] + bf2f(bv[e]));
-                        if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
-                        else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
-                        else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
-                        if (g.residual) x = rbf(bf2f(rv[e]) + x);
-                        if (g.rowadd) x = rbf(x + bf2f(pv[e]));
-                        o[e] = f2bf(x);
-                    }
-                    *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
-                }
-            }
-        }
-        __syncthreads();                                           // the staging image is read: the next tile's DMA may overwrite it
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // 32-deep k-stages: the same LDS-DMA structure with BK = 32, so a 256x128 stage is 24 KB and three of them (72 KB)
 // let TWO workgroups share a CU (<= 128 VGPRs each): while one workgroup's waves are parked on their vmcnt/barrier
 // (39-47 % of wave cycles in the 64-deep kernel, profiles/r01_pmc_mfma_vit32.json) the other one computes.
@@ -1119,14 +1003,6 @@ static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
 static int g_tile_p288 = 1;      // tuning "tile_p288": persistent 288x256 kernel where its decomposition fits (0: round-2 variants only; n > 1: efficiency threshold n %)
 extern "C" void aha_gemm_tile_set_p288(int on) { g_tile_p288 = on; }
-// tuning "tower_bg": BACKGROUND tower.  Every LDS-DMA-eligible GEMM runs the 128x128 four-wave kernel: one wave per SIMD at <= 128
-// VGPRs and 96 KB of LDS, so exactly one workgroup fits a CU and 384 VGPRs per SIMD + 64 KB of LDS stay free - room for any LM
-// workgroup (gate/up: 2 x 192 VGPRs on a SIMD, 26 KB; down: 2 x 168, 50 KB).  For encoding the NEXT batch underneath the LM steps
-// of the current one (bench.py --overlap): the tower needs ~0.13 PF to keep up, the LM kernels never wait for a CU.  Same k order: same bits.
-static int g_tile_bg = 0;
-extern "C" void aha_gemm_tile_set_bg(int on) { g_tile_bg = on; }
-static int g_bg_cus = 256;       // workgroups of the background kernel (one per CU); tuning "bg_cus"
-extern "C" void aha_gemm_tile_set_bg_cus(int n) { g_bg_cus = n > 0 ? n : 256; }
 static int g_tile_epi = 1;       // tuning "tile_epi": 1 = LDS-transposed wide epilogue (default), 0 = direct 8-byte stores
 extern "C" void aha_gemm_tile_set_epi(int on) { g_tile_epi = on; }
 
@@ -1148,19 +1024,6 @@ static hipError_t launch_dma(const GemmTileArgs* g, hipStream_t st) {
     return hipGetLastError();
 }
 
-static hipError_t launch_bg(const GemmTileArgs* g, hipStream_t st) {
-    constexpr int lds_bytes = 3 * 256 * TBK * 2;                  // 96 KB: two workgroups do not fit a CU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_bg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int nblk = ceil_div(g->N, 128) * ceil_div(g->M, 128);
-    hipLaunchKernelGGL(gemm_tile_bg_kernel, dim3(nblk < g_bg_cus ? nblk : g_bg_cus), dim3(256), lds_bytes, st, *g);
-    return hipGetLastError();
-}
-
 static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t st) {
     switch (v) {
         case 2: return launch_dma<4, 4, 4, 2, 3, true>(g, st);   // 256x128, 8 waves, 144 KB (1 per CU), DMA/MFMA interleave
@@ -1172,8 +1035,6 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
         case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
-        case 15: return launch_dma<4, 4, 2, 2, 3, false, 4>(g, st);   // 128x128, FOUR waves (one per SIMD, <= 128 VGPRs), 96 KB (1 per CU): non-persistent form of the background kernel (sweeps)
-        case 16: return launch_bg(g, st);                         // the background tower kernel: the same tile, persistent, one workgroup per CU
         case 14: return launch_ps64(g, st);                      //  64x64, software-pipelined k-steps, 64 KB (2 per CU): the latency path
         case 12: return aha_gemm_tile_p288_ok(g) && g->wide_epi ? aha_gemm_tile_p288(g, st) : launch_dma32<4, 4, 4, 2, 3>(g, st);   // persistent 288x256 (gemm_tile_p.hip)
         default: return hipErrorInvalidValue;
@@ -1204,7 +1065,6 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
         const int nblk_l = ceil_div(g->N, 128) * ceil_div(g->M, 256);
         const float util = (float)nblk_l / (256.f * ceil_div(nblk_l, 256));
         int v = g_tile_dma;
-        if (g_tile_bg && v == 1) return launch_dma_variant(g_tile_bg == 2 ? 15 : 16, g, st);
         if (v == 10) {                                   // experiment: auto, but 256x256 (fewest operand bytes) on wide large grids
             const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
             v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;

@@ -1,5 +1,5 @@
-// gemm_ws_body.h -- the weight-streaming skinny-GEMM workgroup body shared by gemm_ws.hip (one launch per GEMM) and
-// lm_fused.hip (several GEMM phases inside one persistent launch).  See gemm_ws.hip for the design notes.
+// gemm_ws_body.h -- the weight-streaming skinny-GEMM workgroup body of gemm_ws.hip (one launch per GEMM).  See gemm_ws.hip for the
+// design notes.
 #pragma once
 #include "aha_kernels.h"
 

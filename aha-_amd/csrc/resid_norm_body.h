@@ -1,4 +1,4 @@
-// resid_norm_body.h -- split-K reduce + residual add + RMSNorm of one row, shared by elementwise.hip and lm_fused.hip.
+// resid_norm_body.h -- split-K reduce + residual add + RMSNorm of one row (elementwise.hip: resid_norm_kernel).
 #pragma once
 #include "aha_kernels.h"
 
@@ -17,9 +17,9 @@ static __device__ __forceinline__ float block_sum_any(float v, float* red) {
 }
 
 // One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
-// row) and by the fused MLP-block kernel (lm_fused.hip).  All threads of the workgroup must call it together.
-// XN_SC1: store xn write-through (buffer_store ... sc1) because another workgroup of the SAME launch reads it behind a grid
-// barrier without a release fence (lm_fused.hip).
+// row).  All threads of the workgroup must call it together.
+// XN_SC1: store xn write-through (buffer_store ... sc1) for a consumer workgroup of the SAME launch (in-launch hand-offs were
+// measured and dropped in rounds 2-4; the flag stays false in the shipped kernels).
 template <bool XN_SC1 = false>
 static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, const int row, float* red) {
     const int nch = a.H >> 3;

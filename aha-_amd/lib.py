@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaha_amd.so")
+LIB_PATH = os.environ.get("AHA_AMD_LIB") or os.path.join(_HERE, "libaha_amd.so")     # AHA_AMD_LIB: another build of the same ABI (A/B timing of kernel variants)
 
 
 class ModelDesc(C.Structure):

@@ -52,9 +52,6 @@ def parse():
                    help="encode batch k+1 on a second HIP stream while the LM scores batch k (round 3: measured 1.8 %% SLOWER than serial with "
                         "the persistent tower kernels, which hold every CU for a whole GEMM; default off)")
     p.add_argument("--no-overlap", action="store_true", help="(default now; kept for old command lines)")
-    p.add_argument("--tower-bg", type=int, default=0,
-                   help="with --overlap: 1 = encode on the background tower kernels (one four-wave workgroup per CU, LM workgroups fit "
-                        "beside them); measured zero-sum like every overlap here (profiles/r03_overlap_background_tower.txt)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget: frames are scored until it is spent (at most --frames)")
     p.add_argument("--force-dist", action="store_true",
                    help="initialise torch.distributed even for one rank (exercises the RCCL barrier / all-gather / all-reduce path)")
@@ -116,17 +113,29 @@ def pmc_traffic(kernel_prefix, workload):
     """HBM bytes per launch of a kernel from the newest committed PMC summary (counters cannot be collected from inside the
     process being measured) - only from a counter run of the SAME workload as the timed one: a summary row carries the
     workload it was collected on ("static_1stream", "static_8stream", "sink_1stream_steady", "sink_8stream_steady"); rows of any
-    other workload, or a summary that does not say, give None."""
-    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    other workload, or a summary that does not say, give None.  `kernel_prefix` may be a tuple: the launches of one timed group
+    (cache attention + its combine kernel) - their bytes are added, and every one of them must have a row."""
+    prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+    for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         # the round-2 file was collected on static-cache runs only (tools/pmc_round.sh of that round), 1 and 8 streams merged per kernel
-        for k in d["kernels"]:
-            wl = k.get("workload", d.get("workload", "static_1stream+static_8stream"))
-            if kernel_prefix in k["kernel"] and workload in wl.split("+"):
-                return k["hbm_bytes_per_launch"], name
+        total = 0
+        for pre in prefixes:
+            hit = None
+            for k in d["kernels"]:
+                wl = k.get("workload", d.get("workload", "static_1stream+static_8stream"))
+                if pre in k["kernel"] and workload in wl.split("+"):
+                    hit = k["hbm_bytes_per_launch"]
+                    break
+            if hit is None:
+                total = None
+                break
+            total += hit
+        if total is not None:
+            return total, name
     return None, None
 
 
@@ -181,10 +190,8 @@ class Workload:
     """B streams x F frames per step on one GPU: batched vision encode on a second HIP stream (double-buffered embeddings,
     events both ways) while the LM scores the previous batch; every batch's encode and all of its LM steps are timed."""
 
-    def __init__(self, rt, cfg, dev, B, F, cache, window, sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream, gather=None,
-                 tower_bg=False):
+    def __init__(self, rt, cfg, dev, B, F, cache, window, sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream, gather=None):
         self.rt, self.B, self.F, self.tf, self.H = rt, B, F, cfg.frame_num_tokens, cfg.lm.hidden_size
-        self.tower_bg = bool(tower_bg) and vit_stream is not main_stream
         self.frames_all, self.main_stream, self.vit_stream, self.gather = frames_all, main_stream, vit_stream, gather
         self.streams = [rt.open_stream(cache, window, sink, capacity=cfg.lm.max_position_embeddings) for _ in range(B)]
         self.scores_host = torch.empty((F, B, 3), dtype=torch.float32).pin_memory()
@@ -206,13 +213,7 @@ class Workload:
     def encode(self, k):
         with torch.cuda.stream(self.vit_stream):
             self.vit_stream.wait_event(self.emb_free[k & 1])           # the LM is done with this slot
-            if self.tower_bg:
-                self.rt.set_tuning("tower_bg", 1)                      # kernel choice is made at enqueue time
-            try:
-                self.rt.visual_embed(self.frames_all, out=self.emb_buf[k & 1])
-            finally:
-                if self.tower_bg:
-                    self.rt.set_tuning("tower_bg", 0)
+            self.rt.visual_embed(self.frames_all, out=self.emb_buf[k & 1])
             self.emb_ready[k & 1].record(self.vit_stream)
 
     def run(self, n_steps):
@@ -390,9 +391,8 @@ def main():
         loc = scores_dev if a.backend == "nccl" else scores_dev.cpu()
         return gather_scores_async(loc, n_streams_global)         # handle; .result() -> [F, B*world, 3] in global stream order
 
-    tower_bg = (not a.no_overlap) and a.tower_bg == 1
     wl = Workload(rt, cfg, dev, B, F, cache, a.window, a.sink, frames_all, prefix_ids, query_ids, main_stream, vit_stream,
-                  gather if use_dist else None, tower_bg=tower_bg)
+                  gather if use_dist else None)
 
     def sync():
         if use_dist:
@@ -462,10 +462,13 @@ def main():
         return e0.elapsed_time(e1) / reps
     emb_v = emb_last.view(B, F, tf, H)
 
+    # (on a frozen TrulyStaticCache - the headline - these steps change no stream state; with --cache none or a sink / sliding
+    # policy they would append 3 F tf keys behind the measurement and can run a growing stream past the RoPE table, so such runs
+    # carry no whole-LM-step / whole-step fractions)
     def lm_pass():
         for i in range(F):
             rt.lm_step(wl.streams, emb_v[:, i].contiguous(), out=wl.scores_dev[i])
-    lm_ms_per_step = ev_ms(lm_pass, 2) / F
+    lm_ms_per_step = ev_ms(lm_pass, 2) / F if a.cache == "static" else None
     vit_ms = ev_ms(lambda: rt.visual_embed(frames_all), 3)
 
     # per-kind GEMM breakdown of one LM step (diagnostic, outside the timed region)
@@ -516,16 +519,17 @@ def main():
                              + v.hidden_size * H + H * H)
         lm_bytes = wb + kvb
         step_ms = dt / a.steps * 1e3
-        rf["lm_step"] = {"bound": "hbm", "what": f"one whole LM step (28 layers + heads, B={B}, T={tf}): weights + K/V bytes / its time by HIP events",
-                         "achieved": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": lm_ms_per_step, "algorithmic_bytes": lm_bytes}
+        if lm_ms_per_step is not None:
+            rf["lm_step"] = {"bound": "hbm", "what": f"one whole LM step (28 layers + heads, B={B}, T={tf}): weights + K/V bytes / its time by HIP events",
+                             "achieved": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": lm_bytes / (lm_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": lm_ms_per_step, "algorithmic_bytes": lm_bytes}
         rf["vision"] = {"bound": "mfma", "what": f"tower + projector + pool of {B * F} frames: algorithmic flops / its time by HIP events",
                         "achieved": vit_flops / (vit_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": vit_flops / (vit_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "ms": vit_ms, "algorithmic_flops": vit_flops}
         rf["step"] = {"bound": "hbm", "what": "the whole timed step (vision batch + F LM steps): algorithmic HBM bytes / ms_per_step",
                       "achieved": (F * lm_bytes + vit_w_bytes) / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": (F * lm_bytes + vit_w_bytes) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "lm_share_of_step": F * lm_ms_per_step / step_ms, "vision_share_of_step": vit_ms / step_ms}
+                      "lm_share_of_step": F * lm_ms_per_step / step_ms if lm_ms_per_step is not None else None, "vision_share_of_step": vit_ms / step_ms}
         out = {
             "metric": "frames/sec scored (whole node)", "value": total_frames / dt, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -691,8 +695,8 @@ def sink_w2048_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids, main_st
     r_ms, r_n, r_by = timed_kind(rt, wl, emb, 5)
     out = {"workload": f"1 stream, SinkCache W=2048 sink=32 at steady state (evicting every step), {F} frames/step",
            "frames_per_s": F * steps / dt, "ms_per_step": dt / steps * 1e3,
-           "roofline_attention": roofline_hbm("attn_fwd_kernel<128,true> + attn_combine_kernel (one layer: 2,048 keys x 4 KV heads, K and V read once)",
-                                              a_ms, a_n, a_by, "attn_fwd_kernel<128, true>", "sink_1stream_steady"),
+           "roofline_attention": roofline_hbm("attn_fwd_kernel<128,true> + attn_combine_kernel (one layer: 2,048 keys x 4 KV heads, K and V read once; traffic: both kernels)",
+                                              a_ms, a_n, a_by, ("attn_fwd_kernel<128, true>", "attn_combine_kernel"), "sink_1stream_steady"),
            "roofline_rerotation": roofline_hbm("sink_rerotate_kernel<128> (all 28 layers: kept keys read + written in place)", r_ms, r_n, r_by,
                                                "sink_rerotate_kernel", "sink_1stream_steady")}
     wl.close()
@@ -742,8 +746,8 @@ def growing_600_datum(rt, cfg, dev, a, frames_all, prefix_ids, query_ids):
            "frames_per_s": n_frames / dt, "ms_total": dt * 1e3, "lm_step_ms_last_batch": tail_ms, "keys_at_end": st.get_seq_length(),
            "kv_bytes_per_step_at_end": kvb, "weight_bytes_per_step": wb,
            "lm_step_hbm_frac_at_end": (wb + kvb) / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "roofline_attention": roofline_hbm("attn_lm_kernel<128,8> + attn_combine16_kernel at ~21.7k keys (one layer: K and V of 4 KV heads read once; traffic: the attention kernel alone)",
-                                              a_ms, a_n, a_by, "attn_lm_kernel<128, 8>", "growing_1stream_tail")}
+           "roofline_attention": roofline_hbm("attn_lm_kernel<128,8> + attn_combine16c_kernel at ~21.7k keys (one layer: K and V of 4 KV heads read once; traffic: both kernels)",
+                                              a_ms, a_n, a_by, ("attn_lm_kernel<128, 8>", "attn_combine16c_kernel"), "growing_1stream_tail")}
     st.close()
     return out
 
@@ -814,7 +818,8 @@ def eight_stream_datum(rt, cfg, dev, a, B2, prefix_ids, query_ids, main_stream, 
            "lm_step_mfma_frac": (fl / (lm_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if fl else None,
            "lm_step_hbm_frac": (wb + kvb) / (lm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "roofline_gate_up": rl,
-           "roofline_attention": roofline_hbm("cache attention (+ combine) at 8 streams x 2,048 keys (one layer)", a_ms, a_n, a_by)}
+           "roofline_attention": roofline_hbm("attn_lm_kernel<128,8> + attn_combine16_kernel at 8 streams x 2,048 keys (one layer; traffic: both kernels)",
+                                              a_ms, a_n, a_by, ("attn_lm_kernel<128, 8>", "attn_combine16_kernel"), "sink_8stream_steady")}
     wl.close()
     return out
 

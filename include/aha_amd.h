@@ -101,7 +101,7 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *   "kc_small"        k-steps per pipeline chunk of the small split-K GEMMs (4 or 8)
  *   "attn_split_len"  keys per attention split (0 = heuristic)      "attn_tpw"  query tiles per wave of the dense (ViT) attention
  *   "tile_dma"        tiled-GEMM variant (0 register-staged, 1 auto, >= 2 forced variant id)
- *   "use_graph"       1: replay frozen static-cache steps from a captured HIP graph      "fuse_static" / "fuse_mlp"  experiments
+ *   "use_graph"       1: replay frozen static-cache steps from a captured HIP graph      "fuse_static"  experiment
  *   "time_gemm"       bit k: bracket GEMM kind k's launches with HIP events (aha_lm_last_gemm_time); such steps are launched
  *                     directly, not replayed from a graph, so the events are live
  *   "pool_subset"     1 (default): the projector runs only on the patch rows that bilinear pooling with an even integer stride samples

@@ -116,12 +116,15 @@ def _frames_batch(S, i0, n):
     return torch.stack(out)
 
 
-def _long_stream(cfg, rt, policy, n_frames, keep_first):
-    tf, H, S = cfg.frame_num_tokens, cfg.lm.hidden_size, cfg.vision.image_size
-    st = rt.open_stream(policy, 2048, 32)
-    rt.lm_step([st], rt.embed_tokens(make_token_ids(20, cfg.lm.vocab_size, seed=101)).view(1, -1, H))
+def _long_streams(cfg, rt, policies, n_frames, keep_first):
+    """The policies' streams stepped TOGETHER (one batched LM step of len(policies) x tf rows per frame: a row's bits do not depend on its
+    batch below 129 rows, tests/test_gpu_parity.py) over the same counter-based frames: one pass of vision batches and one weight pass
+    per frame for all of them.  Returns per policy (scores [n, 3], (seq_len, seen_tokens)) and the first keep_first frames' embeddings."""
+    tf, H, S, P = cfg.frame_num_tokens, cfg.lm.hidden_size, cfg.vision.image_size, len(policies)
+    sts = [rt.open_stream(p, 2048, 32) for p in policies]
+    rt.lm_step(sts, rt.embed_tokens(make_token_ids(20, cfg.lm.vocab_size, seed=101)).view(1, -1, H).expand(P, -1, -1).contiguous())
     pre = rt.embed_tokens(make_token_ids(35, cfg.lm.vocab_size, seed=100)).view(1, -1, H)
-    scores = torch.empty((n_frames, 3), device="cuda")
+    scores = torch.empty((n_frames, P, 3), device="cuda")
     kept = []
     for i0 in range(0, n_frames, 32):
         n = min(32, n_frames - i0)
@@ -130,63 +133,97 @@ def _long_stream(cfg, rt, policy, n_frames, keep_first):
             kept.append(emb[:max(0, min(n, keep_first - i0))].cpu())
         for j in range(n):
             x = emb[j:j + 1] if i0 + j else torch.cat([pre, emb[:1]], 1)
-            scores[i0 + j] = rt.lm_step([st], x.contiguous())[0]
+            rt.lm_step(sts, x.expand(P, -1, -1).contiguous(), out=scores[i0 + j])
     sc = scores.cpu()
-    info = (st.get_seq_length(), st.seen_tokens)
-    st.close()
-    return sc, (torch.cat(kept) if kept else None), info
+    info = [(st.get_seq_length(), st.seen_tokens) for st in sts]
+    for st in sts:
+        st.close()
+    return [sc[:, k].contiguous() for k in range(P)], (torch.cat(kept) if kept else None), info
 
 
-def _oracle_prefix(cfg, w_cpu, policy, emb, hip_scores):
-    """Replay the first frames through the oracle (bf16 and fp32) on the same embeddings; per-score deviations."""
+def _oracle_prefix(cfg, w_cpu, policy, emb, want_fp32=True):
+    """Replay the first frames through the oracle (bf16, and fp32 for the noise band) on the same embeddings: the oracle's scores per
+    frame, [n, 3] each (the fp32 ones None without want_fp32), and the cache length at the end."""
     from oracle.cache_policies import make_policy
     from oracle.qwen2_live import OracleLM, frame_scores
     H = cfg.lm.hidden_size
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    ob, o32 = OracleLM(cfg.lm, w_cpu, torch.bfloat16), OracleLM(cfg.lm, w_cpu, torch.float32)
+    ob = OracleLM(cfg.lm, w_cpu, torch.bfloat16)
+    o32 = OracleLM(cfg.lm, w_cpu, torch.float32) if want_fp32 else None
     cb, c32 = make_policy(policy, 2048, 32), make_policy(policy, 2048, 32)
     q = ob.embed_tokens(make_token_ids(20, cfg.lm.vocab_size, seed=101)).view(1, -1, H)
     pre = ob.embed_tokens(make_token_ids(35, cfg.lm.vocab_size, seed=100)).view(1, -1, H)
     ob.step(q, cb)
-    o32.step(q.float(), c32)
-    dev, band = [], []
+    if o32 is not None:
+        o32.step(q.float(), c32)
+    sb, s32 = [], []
     for i in range(emb.shape[0]):
         x = emb[i:i + 1] if i else torch.cat([pre, emb[:1]], 1)
-        sb, s32 = _rel(frame_scores(ob.step(x, cb))), _rel(frame_scores(o32.step(x.float(), c32)))
-        gs = _rel(hip_scores[i:i + 1])
-        dev.append((gs - s32).abs()[0])
-        band.append((sb - s32).abs()[0])
-    return torch.stack(dev), torch.stack(band), cb.get_seq_length()
+        sb.append(_rel(frame_scores(ob.step(x, cb)))[0])
+        if o32 is not None:
+            s32.append(_rel(frame_scores(o32.step(x.float(), c32)))[0])
+    return torch.stack(sb), (torch.stack(s32) if s32 else None), cb.get_seq_length()
 
 
-def test_config2_sink_cache_10k_frame_stream_with_oracle_prefix(bench_rt):
-    """SinkCache(W=2048, sink=32), 10,000 frames at full model size: bookkeeping exact, scores finite, and the first 80
-    frames (through the first evictions and re-rotations, from frame ~56) replayed through the oracle."""
+def test_config2_sink_and_sliding_10k_frame_streams_with_oracle_prefixes(bench_rt):
+    """configs[2]: SinkCache(W=2048, sink=32) AND SlidingWindowCache(W=2048) over 10,000 frames at full model size, the two streams
+    stepped together (one vision pass, one weight pass per frame; the sliding window turns over ~175 times, SinkCache evicts and
+    re-rotates 1,980 keys x 28 layers on ~9,940 steps): bookkeeping exact, scores finite, the first 64 / 60 frames (through the first
+    evictions, from frame ~56) replayed through the oracle, and a solo re-run of each policy's first 300 frames reproduces the batched
+    run bit for bit (graph replay, ring state, re-used buffers, batched == solo).
+
+    The oracle replays (CPU, ~1 s per frame) run on the main thread WHILE a worker thread drives the 10,000-frame HIP pass (the context
+    is used by one thread at a time: the main thread touches it only before the worker starts and after it has joined).  On SURVEY
+    8d's weights 28 untrained layers amplify every rounding chaotically, so |hip - oracle_fp32| and |oracle_bf16 - oracle_fp32| are samples
+    of the same noise: the assertions compare MEANS and medians over >= 180 samples, and the SlidingWindowCache stream,
+    replayed in bf16 only, is held to the band the SinkCache replay measured (the band is a property of weights and depth)."""
+    import threading
     cfg, rt, w_cpu = bench_rt
-    n = 10000
-    sc, emb, (seq_len, seen) = _long_stream(cfg, rt, "default_sink", n, keep_first=80)
-    assert torch.isfinite(sc).all() and seq_len == 2048 and seen == 20 + 35 + n * cfg.frame_num_tokens
-    print("sink 10k sha256", hashlib.sha256(sc.numpy().tobytes()).hexdigest()[:16])
-    dev, band, olen = _oracle_prefix(cfg, w_cpu, "default_sink", emb, sc[:80])
-    assert olen == 2048
-    assert dev.median().item() <= max(SCORE_TOL, 2.0 * band.median().item()), (dev.median().item(), band.median().item())
-    assert dev.max().item() <= max(SCORE_TOL, 2.0 * band.max().item()), (dev.max().item(), band.max().item())
+    n, n_sink, n_slide = 10000, 64, 60
+    tf, H, S = cfg.frame_num_tokens, cfg.lm.hidden_size, cfg.vision.image_size
+    emb = rt.visual_embed(_frames_batch(S, 0, 64)).view(64, tf, H).cpu()      # the same 32-frame batches the stream below encodes
+    box = {}
 
-
-def test_config2_sliding_window_10k_frames_with_oracle_prefix(bench_rt):
-    """SlidingWindowCache(W=2048), configs[2]'s 10,000 frames (the window turns over ~175 times), first 64 frames against the
-    oracle (the window starts to slide at frame ~56)."""
-    cfg, rt, w_cpu = bench_rt
-    n = 10000
-    sc, emb, (seq_len, seen) = _long_stream(cfg, rt, "sliding_window", n, keep_first=64)
-    assert torch.isfinite(sc).all() and seq_len == 2048 and seen == 20 + 35 + n * cfg.frame_num_tokens
-    dev, band, olen = _oracle_prefix(cfg, w_cpu, "sliding_window", emb, sc[:64])
-    assert olen == 2048
+    def hip_pass():
+        try:
+            box["out"] = _long_streams(cfg, rt, ["default_sink", "sliding_window"], n, keep_first=64)
+        except BaseException as e:                                             # re-raised on the main thread
+            box["err"] = e
+    worker = threading.Thread(target=hip_pass, name="hip-10k")
+    worker.start()
+    try:
+        sb_k, s32_k, olen_k = _oracle_prefix(cfg, w_cpu, "default_sink", emb[:n_sink])
+        sb_s, _, olen_s = _oracle_prefix(cfg, w_cpu, "sliding_window", emb[:n_slide], want_fp32=False)
+    finally:
+        worker.join()
+    if "err" in box:
+        raise box["err"]
+    (sc_sink, sc_slide), emb_stream, ((len_k, seen_k), (len_s, seen_s)) = box["out"]
+    assert torch.equal(emb_stream, emb)
+    want_seen = 20 + 35 + n * tf
+    assert torch.isfinite(sc_sink).all() and len_k == 2048 and seen_k == want_seen
+    assert torch.isfinite(sc_slide).all() and len_s == 2048 and seen_s == want_seen
+    print("sink 10k sha256", hashlib.sha256(sc_sink.numpy().tobytes()).hexdigest()[:16],
+          "sliding 10k sha256", hashlib.sha256(sc_slide.numpy().tobytes()).hexdigest()[:16])
+    assert not torch.equal(sc_sink[100:], sc_slide[100:])               # the policies really differ once they evict
+    assert olen_k == 2048 and olen_s == 2048
+    dev, band = (_rel(sc_sink[:n_sink]) - s32_k).abs(), (sb_k - s32_k).abs()
+    print(f"SinkCache 10k stream, first {n_sink} frames: |hip - fp32| mean {dev.mean().item():.2e} median {dev.median().item():.2e} max "
+          f"{dev.max().item():.2e}; |oracle_bf16 - fp32| mean {band.mean().item():.2e} median {band.median().item():.2e} max {band.max().item():.2e}")
+    assert dev.numel() >= 180
+    assert dev.mean().item() <= max(SCORE_TOL, 2.0 * band.mean().item()), (dev.mean().item(), band.mean().item())
     assert dev.median().item() <= max(SCORE_TOL, 2.0 * band.median().item()), (dev.median().item(), band.median().item())
-    assert dev.max().item() <= max(SCORE_TOL, 2.0 * band.max().item()), (dev.max().item(), band.max().item())
-    # and the run is reproducible bit for bit over its first 300 frames (graph replay, ring state, re-used buffers)
-    sc2, _, _ = _long_stream(cfg, rt, "sliding_window", 300, keep_first=0)
-    assert torch.equal(sc2, sc[:300])
+    # two bf16 evaluations are each one band away from the exact answer: their distance is held to sqrt(2) x 2 bands
+    d_s = (_rel(sc_slide[:n_slide]) - sb_s).abs()
+    print(f"SlidingWindowCache 10k stream, first {n_slide} frames: |hip - oracle_bf16| mean {d_s.mean().item():.2e} median {d_s.median().item():.2e} "
+          f"max {d_s.max().item():.2e} (band from the SinkCache replay)")
+    assert d_s.numel() >= 180
+    assert d_s.mean().item() <= max(SCORE_TOL, 3.0 * band.mean().item()), (d_s.mean().item(), band.mean().item())
+    # before the window slides (frame < 56) the two policies hold the same keys: identical scores
+    assert torch.equal(sc_sink[:50], sc_slide[:50])
+    for policy, sc in (("default_sink", sc_sink), ("sliding_window", sc_slide)):
+        (sc2,), _, _ = _long_streams(cfg, rt, [policy], 300, keep_first=0)
+        assert torch.equal(sc2, sc[:300]), policy
 
 
 # ---------------------------------------------------------------------------------------------------------------------

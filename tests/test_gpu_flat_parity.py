@@ -40,6 +40,7 @@ from ulp import rms, ulp_error  # noqa: E402
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAT_TOL = 1e-3                 # BASELINE.json north_star: "within 1e-3 (bf16) on identical frame sequences"
+HIDDEN_REL_L2_TOL = 0.05        # provisional until measured on MI355X (set to ~2.5x the measured maximum); scale-free, unlike the scores
 N_FRAMES = 84                   # 20 + 35 + 84 x 36 = 3,079 keys on the growing cache (an oracle prefix through >= 3,000 keys)
 STATS = {}
 
@@ -110,27 +111,39 @@ def test_free_running_scores_within_flat_1e3_of_the_bf16_oracle(stable, policy, 
     rt.lm_step([st], rt.embed_tokens(q_ids).view(1, -1, H))
     pre = rt.embed_tokens(pre_ids).view(1, -1, H)
     got = torch.empty((N_FRAMES, 3), device="cuda")
+    hid_hip = torch.empty((N_FRAMES, H), dtype=torch.bfloat16, device="cuda")
     for i in range(N_FRAMES):
         x = emb_hip[i:i + 1] if i else torch.cat([pre, emb_hip[:1]], 1)
         rt.lm_step([st], x.contiguous(), out=got[i:i + 1])
-    got = got.cpu()
+        hid_hip[i] = rt.last_hidden_all(1, x.shape[1])[0, -1]      # final normalised hidden state of the last token (what the heads read)
+    got, hid_hip = got.cpu(), hid_hip.float().cpu()
     seq_hip = st.get_seq_length()
     st.close()
     # oracle side, on ITS OWN embeddings
     pol = make_policy(policy, window or 2048, sink)
     olm.step(olm.embed_tokens(q_ids), pol)
     opre = olm.embed_tokens(pre_ids)
-    want = []
+    want, hid_ref = [], []
     for i in range(N_FRAMES):
         x = emb_ref[i:i + 1] if i else torch.cat([opre, emb_ref[:1]], 1)
-        want.append(frame_scores(olm.step(x, pol))[0])
-    want = torch.stack(want)
+        o = olm.step(x, pol)
+        want.append(frame_scores(o)[0])
+        hid_ref.append(o["hidden"][0, -1].float())
+    want, hid_ref = torch.stack(want), torch.stack(hid_ref)
     d = (got.double() - want.double()).abs()
+    # a bound that does not shrink with the head scale - the FINAL HIDDEN STATE of the scored token itself, free-running,
+    # as a relative L2 distance per frame (scale-free) and in bf16 ulps at the tensor's rms scale.  A wrong eviction row or a
+    # mis-rotated key changes the hidden state of every later frame by tens of percent; two valid bf16 evaluations differ by the
+    # ~1 % per-channel rounding noise of a 56-add residual stream.
+    rel = ((hid_hip - hid_ref).norm(dim=1) / hid_ref.norm(dim=1))
+    e_h = ulp_error(hid_hip, hid_ref, floor=rms(hid_ref))
     key = str(policy)
     STATS[key] = {"frames": N_FRAMES, "window": window, "sink": sink, "seq_len": seq_hip,
                   "max_abs_diff": d.max(0).values.tolist(), "median_abs_diff": d.median(0).values.tolist(),
                   "frac_within_1e-3": (d <= FLAT_TOL).float().mean().item(),
-                  "score_std": want.double().std(0).tolist(), "score_min": want.min(0).values.tolist(), "score_max": want.max(0).values.tolist()}
+                  "score_std": want.double().std(0).tolist(), "score_min": want.min(0).values.tolist(), "score_max": want.max(0).values.tolist(),
+                  "hidden_rel_l2_max": rel.max().item(), "hidden_rel_l2_median": rel.median().item(),
+                  "hidden_ulp_at_scale_max": e_h.max().item(), "hidden_ulp_at_scale_p999": e_h.flatten().quantile(0.999).item()}
     print(f"flat parity [{key}]:", json.dumps(STATS[key]))
     _dump()
     assert seq_hip == pol.get_seq_length()
@@ -138,6 +151,7 @@ def test_free_running_scores_within_flat_1e3_of_the_bf16_oracle(stable, policy, 
         assert seq_hip == window                                   # the window filled and evicted (SinkCache: re-rotations ran)
     assert want.double().std(0).min().item() >= 0.02, "degenerate scores: the regime must keep a real spread"
     assert d.max().item() <= FLAT_TOL, (d.max(0).values.tolist(), d.argmax(0).tolist())
+    assert rel.max().item() <= HIDDEN_REL_L2_TOL, (rel.max().item(), rel.argmax().item())
 
 
 def test_eight_streams_batched_within_flat_1e3_of_the_bf16_oracle(stable):
@@ -184,9 +198,9 @@ def test_eight_streams_batched_within_flat_1e3_of_the_bf16_oracle(stable):
 
 def test_growing_cache_to_600_frames_bookkeeping_and_reproducibility(stable):
     """past_key_values=None (test/inference.py:154-155) for SURVEY.md 8d config 2's 600 frames: the cache grows to 20 + 35 + 600 x 36 =
-    21,655 keys (attention over 16 long key splits, 1.24 GB of K/V per step at the end).  The first 84 frames are the ones the test
+    21,655 keys (attention over up to 64 key splits of 256-384 keys, 1.24 GB of K/V per step at the end).  The first 84 frames are the ones the test
     above holds to the flat 1e-3 against the oracle; here the stream runs on to 600 frames (embeddings recycled): exact bookkeeping,
-    finite scores that keep their spread, and a second run reproduces every bit (graph replay across ~40 key-split shapes, re-used
+    finite scores that keep their spread, and a second run reproduces every bit (graph replay across ~68 key-split shapes - the graph cache holds 128 - and re-used
     partial buffers).  The attention arithmetic at that length has its own flat-bound test (tests/test_gpu_kernels.py)."""
     cfg, rt, olm, emb_hip, emb_ref, _ = stable
     H, V, tf = cfg.lm.hidden_size, cfg.lm.vocab_size, cfg.frame_num_tokens

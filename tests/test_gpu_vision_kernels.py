@@ -252,37 +252,6 @@ def test_every_encoder_layer_teacher_forced(which, request):
     _note(f"{which} tower free-running ({len(taps)} layers)", e)
 
 
-def test_background_tower_kernels_give_the_same_embeddings(vit_l):
-    """tuning tower_bg (bench.py --overlap --tower-bg 1): 128x128 four-wave persistent tile GEMM + persistent restaging attention,
-    one workgroup per CU - same k order and the same attention body, so the embeddings must not move by a bit (1 and 5 frames:
-    ragged last tiles included); tower_bg = 2 is the same tile with one workgroup per tile."""
-    cfg, _, rt = vit_l
-    from aha_amd.synth import make_frames
-    for n in (1, 5):
-        fr = make_frames(n, cfg.vision.image_size, seed=11 + n).cuda()
-        ref = rt.visual_embed(fr).clone()
-        try:
-            for mode in (1, 2):
-                rt.set_tuning("tower_bg", mode)
-                assert torch.equal(rt.visual_embed(fr), ref), (n, mode)
-        finally:
-            rt.set_tuning("tower_bg", 0)
-
-
-def test_background_tower_on_72_wide_heads_gives_the_same_embeddings(so400m):
-    """head dims 65..96 run their own dense template, which has no background form - with tower_bg set they take the
-    128-wide template's (zero padding is exact, so the bits cannot depend on the choice).  so400m geometry: 729 keys x 16 heads of 72."""
-    cfg, _, rt = so400m
-    from aha_amd.synth import make_frames
-    fr = make_frames(2, cfg.vision.image_size, seed=21).cuda()
-    ref = rt.visual_embed(fr).clone()
-    try:
-        rt.set_tuning("tower_bg", 1)
-        assert torch.equal(rt.visual_embed(fr), ref)
-    finally:
-        rt.set_tuning("tower_bg", 0)
-
-
 def test_pool_and_layernorm_operators_refuse_shapes_their_kernels_cannot_serve(vit_l):
     """aha_pool_forward works in 8-channel chunks and, for avg / max pooling, reads rows (oy*stride + dy): channel counts
     that are not multiples of 8, a non-positive stride or a window that leaves the grid are refused, not executed; aha_layernorm_forward

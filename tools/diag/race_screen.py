@@ -23,9 +23,8 @@ for M, N, K in [(18432, 3072, 1024), (18432, 1024, 4096), (9792, 4096, 1024), (1
     ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     out = torch.empty_like(ref)
     assert lib.aha_dev_gemm_tile(A.data_ptr(), W.data_ptr(), ref.data_ptr(), M, N, K, 0 if M < 4000 else 8, st) == 0
-    for variant, piped in ((12, 1), (12, 0), (14, 1), (16, 1)):     # 16 = the persistent background tile kernel (tower_bg)
+    for variant, piped in ((12, 1), (12, 0), (14, 1)):
         if variant == 14 and M > 2304: continue
-        if variant == 16 and (K % 64 or M > 20000): continue
         lib.aha_gemm_tile_p288_set_pipelined(piped)
         n_bad = 0
         for r in range(rounds):
@@ -45,10 +44,5 @@ for n, T in ((32, 576), (9, 500), (64, 576)):
     n_bad = sum(int(not torch.equal(rt.vit_attention(qkv, 16, 64), ref)) for _ in range(rounds))
     total += rounds; bad += n_bad
     print(f"attn_head64 n={n} T={T}: {n_bad} of {rounds} launches differ", flush=True)
-    rt.set_tuning("tower_bg", 1)                          # persistent restaging attention of the background tower
-    n_bad = sum(int(not torch.equal(rt.vit_attention(qkv, 16, 64), ref)) for _ in range(rounds))
-    rt.set_tuning("tower_bg", 0)
-    total += rounds; bad += n_bad
-    print(f"attn_dense_bg n={n} T={T}: {n_bad} of {rounds} launches differ", flush=True)
 print(f"RACE SCREEN: {bad} differing launches of {total}")
 sys.exit(1 if bad else 0)
