@@ -31,6 +31,7 @@ struct GemmTileArgs {
     const bf16* residual; int ldr;   // out = bf16(residual + bf16(lin)); may alias C
     const bf16* rowadd; int rowadd_period, ldra;  // out = bf16(bf16(lin) + rowadd[m % period]) (position embedding)
     int wide_epi;               // set by aha_gemm_tile (tuning "tile_epi"): LDS-transposed 16-byte epilogue of the LDS-DMA kernels
+    const bf16* Wkb;            // set by aha_gemm_tile_p288 from the registry below: the same weight k-blocked [K/32][N][32], or null
 };
 
 // Weight prefetch riders (latency path of the vision tower): extra workgroups of a launch that do nothing but read byte ranges -
@@ -122,6 +123,9 @@ void aha_gemm_tile_set_epi(int on);
 void aha_gemm_tile_set_p288(int on);
 void aha_gemm_tile_p288_set_pipelined(int v);
 hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st);
+void aha_gemm_tile_kb_register(const void* w_rowmajor, const void* w_kblocked, int N, int K);   // k-blocked twin of a tile-GEMM weight (gemm_tile_p.hip); null twin: forget
+void aha_gemm_tile_set_wkb(int on);
+hipError_t aha_rows_to_kblocked(const bf16* in, int rows, int K, int ld, bf16* out, hipStream_t st);
 int aha_gemm_tile_p288_ok(const GemmTileArgs* g);
 float aha_gemm_tile_p288_efficiency(const GemmTileArgs* g, int n_cus);
 void aha_gemm_ws_set_kc_small(int v);

@@ -109,6 +109,7 @@ extern "C" void aha_ctx_destroy(aha_ctx* c) {
     if (c->gen_out) { hipFree(c->gen_out); hipFree(c->gen_tmp); }
     if (c->gen_ev) hipEventDestroy(c->gen_ev);
     for (auto& kv : c->ingest_tabs) if (kv.second.ready) hipEventDestroy(kv.second.ready);
+    for (const void* w : c->kb_keys) aha_gemm_tile_kb_register(w, nullptr, 0, 0);
     for (void* p : c->allocs) hipFree(p);
     for (int k = 0; k < GK_COUNT; ++k)
         for (auto& pr : c->ev[k]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -151,6 +152,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
     else if (k == "tile_p288s") aha_gemm_tile_p288_set_pipelined(value);   // 1 (default): software-pipelined fragment reads in the persistent tile kernel
     else if (k == "tile_p288") aha_gemm_tile_set_p288(value);    // 1 (default): persistent 288x256 tile kernel on the throughput shapes
+    else if (k == "tile_wkb") aha_gemm_tile_set_wkb(value);      // 1 (default): the persistent tile kernel reads registered weights from their k-blocked twins
     else if (k == "tile_epi") aha_gemm_tile_set_epi(value);      // 1 (default): LDS-transposed wide epilogue of the LDS-DMA tile kernels      // 0 off, 1 auto (default), 2 force
     else return fail(c, AHA_E_NOENT, "unknown tuning key " + k);
     return 0;
@@ -178,6 +180,18 @@ static int copy_vec(aha_ctx* c, const TMap& m, const std::string& name, int64_t 
     int rc = dalloc(c, dst, (size_t)n);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(*dst, t->data, n * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// k-blocked twin [K/32][N][32] of a row-major tile-GEMM weight [N][ld] (gemm_tile_p.hip reads it 1 KiB per DMA piece); K % 32 == 0
+static int make_kb_twin(aha_ctx* c, const bf16* w, int N, int K, int ld, hipStream_t st) {
+    if (!w || K % 32 || ld % 8) return 0;
+    bf16* kb = nullptr;
+    int rc = dalloc(c, &kb, (size_t)N * K);
+    if (rc) return rc;
+    HIPCHK(c, aha_rows_to_kblocked(w, N, K, ld, kb, st));
+    aha_gemm_tile_kb_register(w, kb, N, K);
+    c->kb_keys.push_back(w);
     return 0;
 }
 
@@ -268,6 +282,7 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
         if ((rc = dalloc(c, &c->patch_w, (size_t)Dv * c->Kp))) return rc;
         HIPCHK(c, hipMemsetAsync(c->patch_w, 0, (size_t)Dv * c->Kp * 2, st));
         HIPCHK(c, hipMemcpy2DAsync(c->patch_w, (size_t)c->Kp * 2, t->data, (size_t)PP3 * 2, (size_t)PP3 * 2, Dv, hipMemcpyDeviceToDevice, st));
+        if ((rc = make_kb_twin(c, c->patch_w, Dv, c->Kp, c->Kp, st))) return rc;
     }
     if (d.v_kind == AHA_VISION_CLIP) {
         // CLIPVisionEmbeddings: no patch bias; class_embedding; Np + 1 positions with the class token's row FIRST in the
@@ -316,6 +331,9 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
                                        hipMemcpyDeviceToDevice, st));
         }
         if ((rc = copy_vec(c, m, p + "mlp.fc2.bias", Dv, &w.b2, st))) return rc;
+        // k-blocked twins for the persistent tile kernel (throughput path; the latency path's 64x64 kernels read the row-major weights)
+        if ((rc = make_kb_twin(c, w.wqkv, 3 * Dv, Dv, Dv, st)) || (rc = make_kb_twin(c, w.wo, Dv, Dv, Dv, st)) ||
+            (rc = make_kb_twin(c, w.w1, d.v_inter, Dv, Dv, st)) || (rc = make_kb_twin(c, w.w2, Dv, c->Fp, c->Fp, st))) return rc;
     }
     if (m.count("vision.post_layernorm.weight") && m.count("vision.post_layernorm.bias")) {
         if ((rc = copy_vec(c, m, "vision.post_layernorm.weight", Dv, &c->post_ln_w, st))) return rc;
@@ -340,6 +358,7 @@ extern "C" int aha_ctx_load_weights(aha_ctx* c, const aha_tensor_view* tensors, 
     if ((rc = copy_vec(c, m, "mm_projector.0.weight", (int64_t)H * Dv, &c->p0w, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.0.bias", H, &c->p0b, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.2.weight", (int64_t)H * H, &c->p2w, st))) return rc;
+    if ((rc = make_kb_twin(c, c->p0w, H, Dv, Dv, st)) || (rc = make_kb_twin(c, c->p2w, H, H, H, st))) return rc;
     if ((rc = copy_vec(c, m, "mm_projector.2.bias", H, &c->p2b, st))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));      // sources may be freed by the caller after return
     c->weights_loaded = true;

@@ -123,6 +123,7 @@ struct aha_ctx {
     int ev_used[GK_COUNT] = {0};
     double gk_bytes[GK_COUNT] = {0};
     std::vector<void*> allocs;
+    std::vector<const void*> kb_keys;                        // row-major tile-GEMM weights that have a k-blocked twin registered (forgotten on destroy)
 };
 
 struct aha_stream {

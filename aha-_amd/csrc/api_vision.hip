@@ -9,7 +9,7 @@ hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ldw, int 
     GemmTileArgs g;
     g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
     g.residual = residual; g.ldr = ldr; g.rowadd = rowadd; g.rowadd_period = period > 0 ? period : 1; g.ldra = ldra;
-    g.wide_epi = 0;
+    g.wide_epi = 0; g.Wkb = nullptr;
     return aha_gemm_tile(&g, st);
 }
 

@@ -886,6 +886,22 @@ hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo
     hipLaunchKernelGGL(kblocked_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, M, K, out, ldo);
     return hipGetLastError();
 }
+// row-major [rows][ld] (first K columns, K % 32 == 0) -> k-blocked [K/32][rows][32]: what an LDS-DMA piece of 16 rows x 64 B then reads is
+// one contiguous KiB instead of sixteen half cache lines (tile-GEMM weights: gemm_tile_p.hip)
+__global__ void rows_to_kblocked_kernel(const bf16* __restrict__ in, int rows, int K, int ld, bf16* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece of the output
+    if (i >= (long)rows * (K >> 3)) return;
+    const int c = (int)(i & 3);
+    const long rk = i >> 2;
+    const int row = (int)(rk % rows), kt = (int)(rk / rows);
+    *reinterpret_cast<bf16x8*>(out + i * 8) = *reinterpret_cast<const bf16x8*>(in + (long)row * ld + kt * 32 + c * 8);
+}
+hipError_t aha_rows_to_kblocked(const bf16* in, int rows, int K, int ld, bf16* out, hipStream_t st) {
+    if (K % 32 || ld % 8) return hipErrorInvalidValue;
+    const long total = (long)rows * (K >> 3);
+    hipLaunchKernelGGL(rows_to_kblocked_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, rows, K, ld, out);
+    return hipGetLastError();
+}
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(256), 0, st, ids, n, table, H, vocab, out, ldo);

@@ -23,6 +23,7 @@
 // (tests/test_gpu_parity.py::test_tiled_gemm_variants_are_bit_identical).
 #include "aha_kernels.h"
 #include "tile_act.h"
+#include <unordered_map>
 #ifdef AHA_CLOCK_STAMP
 __device__ unsigned long long aha_clock_stamps[4 * 256];   // written by the diagnostic build only; no other code reads it
 #endif
@@ -321,6 +322,10 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
     const int prow = lane >> 2, pslot = lane & 3;                    // 16-B pieces: 16 rows x 4 slots
     const int qrow = lane >> 4, qslot = (lane >> 2) & 3, qbyte = (lane & 3) * 4;   // 4-B quarter piece: 4 rows x 4 slots x 4 dwords
     unsigned poff[PPIECES];
+    // W row-major [N][ldw]: a row's 64-byte piece of k-step s sits 32 s elements into the row.  W k-blocked [K/32][N][32] (g.Wkb, the twin
+    // registered at load): rows are 32 elements apart and a k-step N * 32, so the 16 rows of a piece are ONE contiguous KiB = 8 whole cache
+    // lines instead of 16 half lines - the mid-M LM kernel's operands travel the same way (gemm_wl.hip, -16 % on down_proj).
+    const unsigned wrs = g.Wkb ? 32u : (unsigned)g.ldw, wks = g.Wkb ? (unsigned)g.N * 32u : 32u;
     int d_j = 0, d_k = 0;                                            // prefetch stream position: tile index, k-step
     auto set_tile_offsets = [&](int j) {
         int bm, bn;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int wrow = (wave + 8 * i) * 16 + prow;             // swizzle key: (row >> 2) & 3 with the row index inside its operand
-            poff[i] = (unsigned)min(n0 + wrow, g.N - 1) * (unsigned)g.ldw + ((pslot ^ ((wrow >> 2) & 3)) << 3);
+            poff[i] = (unsigned)min(n0 + wrow, g.N - 1) * wrs + ((pslot ^ ((wrow >> 2) & 3)) << 3);
             const int arow = (wave + 8 * i) * 16 + prow;
             poff[2 + i] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((pslot ^ ((arow >> 2) & 3)) << 3);
         }
@@ -337,12 +342,12 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
         poff[4] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((qslot ^ ((arow >> 2) & 3)) << 3);
     };
     const char* Ab = reinterpret_cast<const char*>(g.A);
-    const char* Wb = reinterpret_cast<const char*>(g.W);
+    const char* Wb = reinterpret_cast<const char*>(g.Wkb ? g.Wkb : g.W);
     // issue piece i of the prefetch stream's current k-step into stage `st`
     auto dma_piece = [&](int i, int st, int k0) {
         bf16* sb = lds + st * PSTAGE;
         if (i < 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Wb + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + (PBM + (wave + 8 * i) * 16) * PBK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Wb + ((size_t)poff[i] + (size_t)(k0 >> 5) * wks) * 2), (lptr_t)(sb + (PBM + (wave + 8 * i) * 16) * PBK), 16, 0, 0);
         else if (i < 4)
             __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + ((wave + 8 * (i - 2)) * 16) * PBK), 16, 0, 0);
         else
@@ -536,7 +541,24 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
 static int g_p288_cus = 0;
 static int g_p288_pipelined = 1;   // 1: software-pipelined fragment reads (gemm_tile_p288s_kernel); 0: the plain k-step loop
 extern "C" void aha_gemm_tile_p288_set_pipelined(int v) { g_p288_pipelined = v; }
-extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st) {
+// k-blocked twins of tile-GEMM weights, keyed by the row-major pointer the callers pass (registered by the weight loader, forgotten
+// when their context goes): the kernel's contract stays "W row-major"; the twin only changes where its DMA finds the same bytes.
+struct WkbTwin { const bf16* kb; int N, K; };
+static std::unordered_map<const void*, WkbTwin> g_wkb_map;
+static int g_wkb_on = 1;           // tuning "tile_wkb"
+extern "C" void aha_gemm_tile_kb_register(const void* w, const void* kb, int N, int K) {
+    if (kb) g_wkb_map[w] = WkbTwin{reinterpret_cast<const bf16*>(kb), N, K};
+    else g_wkb_map.erase(w);
+}
+extern "C" void aha_gemm_tile_set_wkb(int on) { g_wkb_on = on; }
+extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g_, hipStream_t st) {
+    GemmTileArgs gg = *g_;
+    gg.Wkb = nullptr;
+    if (g_wkb_on && g_p288_pipelined && !g_wkb_map.empty() && gg.K % 32 == 0) {
+        auto it = g_wkb_map.find(gg.W);
+        if (it != g_wkb_map.end() && it->second.N == gg.N && it->second.K == gg.K) gg.Wkb = it->second.kb;      // the whole matrix, as registered
+    }
+    const GemmTileArgs* g = &gg;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_p288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);

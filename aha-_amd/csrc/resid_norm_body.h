@@ -27,6 +27,10 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
     for (int c0 = 0; c0 < nch; c0 += blockDim.x) {          // one pass when H/8 <= blockDim
         const int c = c0 + threadIdx.x;
         float f8[8];
+        // the norm weight of this thread's chunk is fetched with the slabs, not behind the row reduction's barriers (the compiler keeps a
+        // load on its side of a barrier: it was one more dependent L2 round trip in a kernel that is nothing but round trips)
+        bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < nch && nch <= (int)blockDim.x) wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
         if (c < nch) {
             float lin[8];
             if (a.partial) {
@@ -68,7 +72,6 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
             ss = block_sum_any(ss, red);
             const float rstd = rsqrtf(ss / (float)a.H + a.eps);
             if (c < nch) {
-                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(a.w + c * 8);
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(wv[e]) * rbf(f8[e] * rstd));

@@ -40,7 +40,7 @@ from ulp import rms, ulp_error  # noqa: E402
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FLAT_TOL = 1e-3                 # BASELINE.json north_star: "within 1e-3 (bf16) on identical frame sequences"
-HIDDEN_REL_L2_TOL = 0.05        # provisional until measured on MI355X (set to ~2.5x the measured maximum); scale-free, unlike the scores
+HIDDEN_REL_L2_TOL = 0.05        # scale-free, unlike the scores; measured on MI355X: max 0.031-0.036 per policy, median 0.021-0.024 (profiles/r05_flat_parity_stats.json)
 N_FRAMES = 84                   # 20 + 35 + 84 x 36 = 3,079 keys on the growing cache (an oracle prefix through >= 3,000 keys)
 STATS = {}
 
