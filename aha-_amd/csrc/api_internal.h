@@ -101,7 +101,8 @@ struct aha_ctx {
     int wpb[GK_GEMMS] = {4, 4, 5, 8};
     int attn_split_len = 0;
     int time_gemm = 0;
-    int act_kb = 2;                                         // tuning: k-blocked SwiGLU activation between the mid-M gate/up and down GEMMs
+    int act_kb = 3;                                         // tuning: k-blocked operands between the mid-M kernels: >= 1 the SwiGLU activation (down_proj), >= 2 gate/up's normed input, >= 3 the QKV and o_proj inputs
+    int attn_kb_rows = 0;                                   // rows of the k-blocked attention output the last step left in c->attn_out (0: row-major)
     int act_kb_rows = 0;                                    // rows of the k-blocked activation the last step left in c->act (0: row-major)
     int dev_xkb = 0;                                        // experiment: aha_linear_forward reads X k-blocked ([K/32][ldx rows][32])
     int use_wl = 1;                                         // tuning: mid-M GEMM kernel (gemm_wl.hip) for row chunks above 128 (0: gemm_ws everywhere)

@@ -264,6 +264,12 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     // layout of the SwiGLU activation this step leaves in c->act (a function of M and the tunings only, so a replayed graph
     // agrees with it): k-blocked when both MLP GEMMs run the mid-M kernel on every row chunk
     c->act_kb_rows = (c->act_kb && I % 32 == 0 && ws_all_wl(c, EPI_SWIGLU, M, H) && ws_all_wl(c, EPI_PARTIAL, M, I)) ? M : 0;
+    // ... and [r5] the inputs of the other two mid-M GEMMs: the normed rows a layer hands to the NEXT layer's QKV projection (written k-blocked
+    // by the layer's last resid_norm; the first executed layer reads the row-major rows of the step's first RMSNorm, the last one leaves
+    // row-major rows for the heads), and the attention output o_proj reads (written k-blocked by whichever cache-attention kernel runs).
+    const bool qkv_kb = c->act_kb >= 3 && H % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, H);
+    const bool o_kb = c->act_kb >= 3 && QD % 32 == 0 && Dh % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, QD) && !static_attn && !frozen_all;
+    c->attn_kb_rows = o_kb ? M : 0;
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
@@ -276,7 +282,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             if (q_only) { wq.n_tiles = QD / 16; wq.N = QD; }
             const int nq_ld = w.qkv.n_tiles * 16;
             const int Sq = pick_split(c, GK_QKV, w.qkv, M, 1);      // same split as the full projection: bit-identical q
-            if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st))) return rc;
+            if ((rc = ws_gemm(c, GK_QKV, c->xn, H, M, wq, EPI_PARTIAL, Sq, c->partial, nq_ld, nullptr, 0, nullptr, 0, st, (qkv_kb && l > l_first) ? 1 : 0))) return rc;
             AttnArgs a;
             memset(&a, 0, sizeof(a));
             if (static_attn) {
@@ -310,6 +316,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             a.out = c->attn_out; a.o_bs = (long)T * QD; a.ldo = QD;
             a.part_o = c->part_o; a.part_ml = c->part_ml;
             a.T = T; a.G = G; a.Hkv = d.kv_heads; a.split_len = split_len; a.n_splits = n_splits;
+            a.okb = o_kb ? M : 0;
             a.scale = 1.0f / sqrtf((float)Dh); a.layer = l;
             const bool t_attn = (c->time_gemm >> GK_ATTN) & 1;
             if (t_attn) { if ((rc = timed_begin(c, GK_ATTN, st))) return rc; }
@@ -324,7 +331,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             const int So = pick_split(c, GK_O, w.o, M, 1);
             ResidNormArgs ra;
             memset(&ra, 0, sizeof(ra));
-            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st))) return rc;
+            if ((rc = ws_gemm(c, GK_O, c->attn_out, QD, M, w.o, EPI_PARTIAL, So, c->partial, H, nullptr, 0, nullptr, 0, st, o_kb ? 1 : 0))) return rc;
             ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
             ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
             const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
@@ -343,6 +350,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             }
             ra.S = Sd;
             ra.w = (l + 1 < d.layers) ? c->L[l + 1].ln1 : c->final_norm;
+            ra.xkb = (qkv_kb && l + 1 < l_end) ? M : 0;           // the next executed layer's QKV input
             HIPCHK(c, aha_resid_norm(&ra, M, st));
         }
         // ---- heads on the last token of every stream
@@ -485,7 +493,12 @@ extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream
         case 0: src = c->h; cols = c->d.hidden; break;
         case 1: src = c->xn; cols = c->d.hidden; break;
         case 2: src = c->q_rot; cols = (size_t)c->d.heads * c->d.head_dim; break;
-        case 3: src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
+        case 3:
+            if (c->attn_kb_rows) {                                 // the mid-M path leaves the attention output k-blocked
+                HIPCHK(c, aha_kblocked_to_rows(c->attn_out, c->attn_kb_rows, c->d.heads * c->d.head_dim, (bf16*)out, c->d.heads * c->d.head_dim, st));
+                return 0;
+            }
+            src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
         case 4:
             if (c->act_kb_rows) {                                  // the mid-M path leaves the activation k-blocked
                 HIPCHK(c, aha_kblocked_to_rows(c->act, c->act_kb_rows, c->d.inter, (bf16*)out, c->d.inter, st));

@@ -19,6 +19,13 @@
 #include "aha_kernels.h"
 #include <type_traits>
 
+// LM mode: where a vector of <= 8 channels starting at channel `col` (a multiple of its width) of new token t of stream b goes - row-major
+// [B*T][ldo], or k-blocked [ldo/32][okb rows][32] for the mid-M o_proj GEMM, whose LDS-DMA then pulls contiguous 1-KiB panels (gemm_wl.hip)
+static __device__ __forceinline__ bf16* lm_out_ptr(const AttnArgs& a, const int b, const int t, const int col) {
+    if (a.okb) return a.out + ((long)(col >> 5) * a.okb + (long)b * a.T + t) * 32 + (col & 31);
+    return a.out + b * a.o_bs + (long)t * a.ldo + col;
+}
+
 
 template <int D> struct AttnCfg {
     static constexpr int CPR = D / 8;          // 16-B chunks per K row
@@ -272,11 +279,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, const StepDes
     // o[dt][e] <-> d = dt*16 + 4*q4 + e of row r
     if (a.n_splits == 1) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;        // a row that sees no key (flash-attn-2 mask of a frozen static cache) gives 0
-        bf16* op = a.out + b * a.o_bs + (long)t * a.ldo + head * a.hd + 4 * q4;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt) {
             bf16x4 ov = {f2bf(o[dt][0] * inv), f2bf(o[dt][1] * inv), f2bf(o[dt][2] * inv), f2bf(o[dt][3] * inv)};
-            if (dt * 16 + 4 * q4 < a.hd) *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+            if (dt * 16 + 4 * q4 < a.hd) *reinterpret_cast<bf16x4*>(lm_out_ptr(a, b, t, head * a.hd + dt * 16 + 4 * q4)) = ov;
         }
     } else {
         const int Rpad = RT * 16;
@@ -884,11 +890,10 @@ __global__ __launch_bounds__(64 * NW) void attn_lm_kernel(AttnArgs a, const Step
         if (!row_ok[tt]) continue;
         if (a.n_splits == 1) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;               // a row that sees no key gives 0
-            bf16* op = a.out + b * a.o_bs + (long)trow[tt] * a.ldo + thead[tt] * D + 4 * q4;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 ov = {f2bf(o[tt][dt][0] * inv), f2bf(o[tt][dt][1] * inv), f2bf(o[tt][dt][2] * inv), f2bf(o[tt][dt][3] * inv)};
-                *reinterpret_cast<bf16x4*>(op + dt * 16) = ov;
+                *reinterpret_cast<bf16x4*>(lm_out_ptr(a, b, trow[tt], thead[tt] * D + dt * 16 + 4 * q4)) = ov;
             }
         } else {
             const int Rpad = RT * 16;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256) void attn_combine16_kernel(AttnArgs a, const S
     bf16x8 ov;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ov[e] = f2bf(L > 0.f ? acc[e] / L : 0.f);
-    *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
+    *reinterpret_cast<bf16x8*>(lm_out_ptr(a, b, t, (hk * a.G + g) * D + d0)) = ov;
 }
 
 // More than 16 splits: 4 query rows per 256-thread block, the (up to four) chunks of a row on different threads - every partial load of
@@ -1012,7 +1017,7 @@ __global__ __launch_bounds__(256) void attn_combine16c_kernel(AttnArgs a, const 
     bf16x8 ov;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ov[e] = f2bf(L > 0.f ? acc[e] / L : 0.f);
-    *reinterpret_cast<bf16x8*>(a.out + b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * D + d0) = ov;
+    *reinterpret_cast<bf16x8*>(lm_out_ptr(a, b, t, (hk * a.G + g) * D + d0)) = ov;
 }
 
 // Merge key splits: one block of D threads per (b, kv head, row) - the general form (any head dim, attn_fwd_kernel's partner).
@@ -1048,7 +1053,7 @@ __global__ void attn_combine_kernel(AttnArgs a, const StepDesc* __restrict__ sdp
         comb_merge(M, L, &acc, 1, Mc, Lc, &accc);
     }
     const int g = r / a.T, t = r % a.T;
-    if (d < a.hd) a.out[b * a.o_bs + (long)t * a.ldo + (hk * a.G + g) * a.hd + d] = f2bf(L > 0.f ? acc / L : 0.f);
+    if (d < a.hd) *lm_out_ptr(a, b, t, (hk * a.G + g) * a.hd + d) = f2bf(L > 0.f ? acc / L : 0.f);
 }
 
 static int g_dense_tpw = 0;      // tuning "attn_tpw": query tiles per wave of the dense kernel (0 = auto, 1..3 forced)
