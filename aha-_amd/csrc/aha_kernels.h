@@ -32,6 +32,8 @@ struct GemmTileArgs {
     const bf16* rowadd; int rowadd_period, ldra;  // out = bf16(bf16(lin) + rowadd[m % period]) (position embedding)
     int wide_epi;               // set by aha_gemm_tile (tuning "tile_epi"): LDS-transposed 16-byte epilogue of the LDS-DMA kernels
     const bf16* Wkb;            // set by aha_gemm_tile_p288 from the registry below: the same weight k-blocked [K/32][N][32], or null
+    int akb;                    // persistent tile kernel only: 0 = A row-major [M][lda]; else A is k-blocked [K/32][akb rows][32] (akb == M)
+    int ckb;                    // persistent tile kernel only: 0 = C row-major [M][ldc]; else C is written k-blocked [N/32][ckb rows][32] (the next GEMM's A)
 };
 
 // Weight prefetch riders (latency path of the vision tower): extra workgroups of a launch that do nothing but read byte ranges -
@@ -124,6 +126,7 @@ void aha_gemm_tile_set_epi(int on);
 void aha_gemm_tile_set_p288(int on);
 void aha_gemm_tile_p288_set_pipelined(int v);
 hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st);
+int aha_gemm_tile_will_use_p288(const GemmTileArgs* g);     // 1: aha_gemm_tile would run this shape on the persistent 288x256 kernel (the only one that takes akb / ckb)
 void aha_gemm_tile_kb_register(const void* w_rowmajor, const void* w_kblocked, int N, int K);   // k-blocked twin of a tile-GEMM weight (gemm_tile_p.hip); null twin: forget
 void aha_gemm_tile_set_wkb(int on);
 hipError_t aha_rows_to_kblocked(const bf16* in, int rows, int K, int ld, bf16* out, hipStream_t st);
@@ -151,6 +154,7 @@ hipError_t aha_clip_assemble(const bf16* patches, const bf16* cls, const bf16* p
 hipError_t aha_layernorm(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps, hipStream_t st);
 hipError_t aha_layernorm_pf(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out, int ldo, int M, int D, float eps,
                             const WeightPrefetch* pf, hipStream_t st);   // + weight prefetch riders (latency path); pf may be null
+hipError_t aha_layernorm_kb(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out_kb, int M, int D, float eps, hipStream_t st);   // out k-blocked [D/32][M][32]
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st);
 hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go, int s, int Dv, int frame_rows, hipStream_t st);

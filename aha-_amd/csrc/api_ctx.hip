@@ -141,6 +141,7 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "static_attn") c->static_attn = value;
     else if (k == "pool_subset") c->pool_subset = value;
     else if (k == "vit_prefetch") c->vit_prefetch_rows = value;   // rows up to which the tower's LayerNorm launches carry weight-prefetch riders (0 off)
+    else if (k == "vit_akb") c->vit_akb = value;                  // k-blocked A operands on the tower's throughput path (0: row-major everywhere)
     else if (k == "vit_riders") c->vit_riders = value < 0 ? 0 : (value > 1024 ? 1024 : value);   // rider workgroups per prefetching launch
     else if (k == "vit_alias") c->vit_alias = value;              // diagnostic (tools/diag/vit_alias.py): wrong embeddings on purpose
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph

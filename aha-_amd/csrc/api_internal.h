@@ -113,6 +113,7 @@ struct aha_ctx {
     // operator-level attention (aha_attention_forward): its own descriptor slot ring is the step's (sd_pin / sd_dev)
     int pool_subset = 1;                 // projector only on the patch rows bilinear pooling samples (tuning "pool_subset"; bit-identical)
     int vit_prefetch_rows = 2400;        // tuning "vit_prefetch": tower encodes of up to this many token rows (4 frames of 576) prefetch weights from their LayerNorm launches
+    int vit_akb = 1;                     // tuning "vit_akb": k-blocked activations between the tower's LayerNorm / fc1 and the persistent tile GEMMs
     int vit_riders = 256;                // tuning "vit_riders": rider workgroups per prefetching launch
     int vit_alias = 0;                   // diagnostic: encoder layer l runs layer l % vit_alias's weights (0 = its own): a tower whose weights stay cache-resident
     int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")

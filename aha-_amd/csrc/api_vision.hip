@@ -4,12 +4,16 @@
 // --------------------------------------------------------------------------------------------
 // vision
 // --------------------------------------------------------------------------------------------
+static void tile_args(GemmTileArgs& g, const bf16* A, int lda, int M, const bf16* W, int ldw, int N, int K, bf16* C, int ldc, const bf16* bias,
+                      int act, const bf16* residual, int ldr, const bf16* rowadd, int period, int ldra) {
+    g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
+    g.residual = residual; g.ldr = ldr; g.rowadd = rowadd; g.rowadd_period = period > 0 ? period : 1; g.ldra = ldra;
+    g.wide_epi = 0; g.Wkb = nullptr; g.akb = 0; g.ckb = 0;
+}
 hipError_t tile_gemm(const bf16* A, int lda, int M, const bf16* W, int ldw, int N, int K, bf16* C, int ldc, const bf16* bias,
                             int act, const bf16* residual, int ldr, const bf16* rowadd, int period, int ldra, hipStream_t st) {
     GemmTileArgs g;
-    g.A = A; g.lda = lda; g.M = M; g.W = W; g.ldw = ldw; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.bias = bias; g.act = act;
-    g.residual = residual; g.ldr = ldr; g.rowadd = rowadd; g.rowadd_period = period > 0 ? period : 1; g.ldra = ldra;
-    g.wide_epi = 0; g.Wkb = nullptr;
+    tile_args(g, A, lda, M, W, ldw, N, K, C, ldc, bias, act, residual, ldr, rowadd, period, ldra);
     return aha_gemm_tile(&g, st);
 }
 
@@ -47,6 +51,16 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
     // cache-resident weights, tuning "vit_alias": 1.74).  Riders change no output bit.  Tuning "vit_prefetch" = rows up to which it is on
     // (0: off); the throughput path never prefetches (its GEMMs are not latency-bound and the riders would only take CUs).
     const bool pf = rows <= c->vit_prefetch_rows && c->vit_riders > 0;
+    // Throughput path: where the persistent tile kernel runs a GEMM (aha_gemm_tile_will_use_p288: from 8 frames of 576 patches up), its A
+    // operand travels k-blocked [K/32][rows][32] - written that way by the producer (LayerNorm for QKV and fc1, fc1's epilogue for fc2) -
+    // so that an LDS-DMA piece of 16 rows x 64 B is one contiguous KiB, as for the weights' twins (tuning "vit_akb"; same bits).
+    GemmTileArgs gq, g1, g2;
+    tile_args(gq, c->v_h, Dv, rows, c->V[l0 < d.v_layers ? l0 : 0].wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, 0);
+    tile_args(g1, c->v_h, Dv, rows, c->V[l0 < d.v_layers ? l0 : 0].w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, nullptr, act, nullptr, 0, nullptr, 0, 0);
+    tile_args(g2, c->v_f, c->Fp, rows, c->V[l0 < d.v_layers ? l0 : 0].w2, c->Fp, Dv, c->Fp, c->v_x, Dv, nullptr, ACT_NONE, c->v_x, Dv, nullptr, 0, 0);
+    const bool kb_ok = c->vit_akb && !pf && Dv % 32 == 0;
+    const bool kb_q = kb_ok && aha_gemm_tile_will_use_p288(&gq), kb_1 = kb_ok && aha_gemm_tile_will_use_p288(&g1);
+    const bool kb_2 = kb_1 && c->Fp == d.v_inter && d.v_inter % 32 == 0 && aha_gemm_tile_will_use_p288(&g2);   // no zero-padded columns to keep clean
     const size_t b_qkv = (size_t)3 * Dv * Dv * 2, b_o = (size_t)Dv * Dv * 2, b_1 = (size_t)d.v_inter * Dv * 2, b_2 = (size_t)Dv * c->Fp * 2;
     for (int l = l0; l < l1; ++l) {
         const auto vw = [&](int i) -> const VLayerW& { return c->V[c->vit_alias > 0 ? i % c->vit_alias : i]; };
@@ -55,9 +69,16 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
         if (pf && l == l0) {
             WeightPrefetch p0{{w.wqkv, w.wo, nullptr, nullptr}, {(long)b_qkv, (long)b_o, 0, 0}, c->vit_riders};
             HIPCHK(c, aha_layernorm_pf(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, &p0, st));
-        } else
+        } else if (kb_q)
+            HIPCHK(c, aha_layernorm_kb(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, rows, Dv, d.v_ln_eps, st));
+        else
             HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0, st));
+        {
+            GemmTileArgs g;
+            tile_args(g, c->v_h, Dv, rows, w.wqkv, Dv, 3 * Dv, Dv, c->v_qkv, 3 * Dv, w.bqkv, ACT_NONE, nullptr, 0, nullptr, 0, 0);
+            g.akb = kb_q ? rows : 0;
+            HIPCHK(c, aha_gemm_tile(&g, st));
+        }
         AttnArgs a;
         memset(&a, 0, sizeof(a));
         a.q = c->v_qkv; a.q_bs = (long)T * 3 * Dv; a.ldq = 3 * Dv;
@@ -80,9 +101,17 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
         }
         HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
         HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
-        HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
-        HIPCHK(c, tile_gemm(c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, w.b1, act, nullptr, 0, nullptr, 0, 0, st));
-        HIPCHK(c, tile_gemm(c->v_f, c->Fp, rows, w.w2, c->Fp, Dv, c->Fp, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
+        if (kb_1) HIPCHK(c, aha_layernorm_kb(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, rows, Dv, d.v_ln_eps, st));
+        else HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
+        {
+            GemmTileArgs g;
+            tile_args(g, c->v_h, Dv, rows, w.w1, Dv, d.v_inter, Dv, c->v_f, c->Fp, w.b1, act, nullptr, 0, nullptr, 0, 0);
+            g.akb = kb_1 ? rows : 0; g.ckb = kb_2 ? rows : 0;
+            HIPCHK(c, aha_gemm_tile(&g, st));
+            tile_args(g, c->v_f, c->Fp, rows, w.w2, c->Fp, Dv, c->Fp, c->v_x, Dv, w.b2, ACT_NONE, c->v_x, Dv, nullptr, 0, 0);
+            g.akb = kb_2 ? rows : 0;
+            HIPCHK(c, aha_gemm_tile(&g, st));
+        }
     }
     return 0;
 }

@@ -527,7 +527,8 @@ __global__ void im2col_norm_kernel(const uint8_t* __restrict__ frames, int N, in
 // Infinity Cache when their GEMM starts.  At one frame the tower's kernels are latency-bound chains with HBM almost idle (25 MB
 // of weights per 85 us layer): with the weights cache-resident the encode measures 1.74 ms instead of 2.09 (tuning "vit_alias",
 // tools/diag/vit_alias.py).  Riders change no output bit; with n_riders = 0 the launch is the plain LayerNorm.
-template <int NC, bool PF = false>
+// KB: `out` is written k-blocked [D/32][M][32] (ldo unused) for the persistent tile GEMM that reads it next (gemm_tile_p.hip, akb).
+template <int NC, bool PF = false, bool KB = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__ x, int ldx, const bf16* __restrict__ w,
                                                         const bf16* __restrict__ bias, bf16* __restrict__ out, int ldo,
                                                         int M, int D, float eps, WeightPrefetch pf) {
@@ -570,7 +571,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16* __restrict__
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf((bf2f(v[i][e]) - mean) * rstd * bf2f(wv[e]) + bf2f(bv[e]));
-            *reinterpret_cast<bf16x8*>(out + (long)row * ldo + c * 8) = o;
+            if constexpr (KB) *reinterpret_cast<bf16x8*>(out + ((long)(c >> 2) * M + row) * 32 + (c & 3) * 8) = o;
+            else *reinterpret_cast<bf16x8*>(out + (long)row * ldo + c * 8) = o;
         }
     }
 }
@@ -857,6 +859,16 @@ hipError_t aha_layernorm_pf(const bf16* x, int ldx, const bf16* w, const bf16* b
         else if (nc <= 3) hipLaunchKernelGGL((layernorm_kernel<3>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
         else hipLaunchKernelGGL((layernorm_kernel<8>), grid, blk, 0, st, x, ldx, w, b, out, ldo, M, D, eps, pf);
     }
+    return hipGetLastError();
+}
+hipError_t aha_layernorm_kb(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out_kb, int M, int D, float eps, hipStream_t st) {
+    if ((D & 31) || D > 4096) return hipErrorInvalidValue;
+    const int nc = ceil_div(D >> 3, 64);
+    const WeightPrefetch pf{};
+    const dim3 grid(ceil_div(M, 4)), blk(256);
+    if (nc <= 2) hipLaunchKernelGGL((layernorm_kernel<2, false, true>), grid, blk, 0, st, x, ldx, w, b, out_kb, 0, M, D, eps, pf);
+    else if (nc <= 3) hipLaunchKernelGGL((layernorm_kernel<3, false, true>), grid, blk, 0, st, x, ldx, w, b, out_kb, 0, M, D, eps, pf);
+    else hipLaunchKernelGGL((layernorm_kernel<8, false, true>), grid, blk, 0, st, x, ldx, w, b, out_kb, 0, M, D, eps, pf);
     return hipGetLastError();
 }
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st) {

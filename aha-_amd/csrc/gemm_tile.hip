@@ -1049,6 +1049,18 @@ static hipError_t check_tile_args(const GemmTileArgs* g) {
     return hipSuccess;
 }
 
+// the predicate of aha_gemm_tile's choice of the persistent 288 x 256 kernel, for callers that want to hand it k-blocked operands
+static bool tile_picks_p288(const GemmTileArgs* g) {
+    return g_tile_dma == 1 && (g->K % TBK) == 0 && g->K >= 2 * TBK && g_tile_p288 && g_tile_epi && aha_gemm_tile_p288_ok(g) &&
+           aha_gemm_tile_p288_efficiency(g, 256) >= (g_tile_p288 > 1 ? 0.01f * g_tile_p288 : 0.70f);
+}
+extern "C" int aha_gemm_tile_will_use_p288(const GemmTileArgs* g) {
+    if (g->M <= 0 || g->N <= 0 || check_tile_args(g) != hipSuccess) return 0;
+    GemmTileArgs gg = *g;
+    gg.wide_epi = g_tile_epi;
+    return tile_picks_p288(&gg) ? 1 : 0;
+}
+
 extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
     GemmTileArgs gg = *g_;
     gg.wide_epi = g_tile_epi;
@@ -1069,7 +1081,8 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
             const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
             v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
         }
-        if (v == 1 && g_tile_p288 && g->wide_epi && aha_gemm_tile_p288_ok(g) && aha_gemm_tile_p288_efficiency(g, 256) >= (g_tile_p288 > 1 ? 0.01f * g_tile_p288 : 0.70f)) {
+        if ((g->akb || g->ckb) && !(v == 1 && tile_picks_p288(g))) return hipErrorInvalidValue;   // k-blocked operands: the persistent kernel only (caller asks aha_gemm_tile_will_use_p288 first)
+        if (v == 1 && tile_picks_p288(g)) {
             // throughput shapes whose 288 x 256 decomposition keeps the chip busy (tile padding x round quantisation >= 0.70:
             // every tower and projector GEMM from 8 frames of 576 patches up): the persistent kernel (gemm_tile_p.hip).
             // Tuning "tile_p288" = 0 keeps the round-2 selection below.
@@ -1089,6 +1102,7 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
         }
         return launch_dma_variant(v, g, st);
     }
+    if (g->akb || g->ckb) return hipErrorInvalidValue;
     if (nblk128 >= 384) {            // enough 128x128 tiles to fill 256 CUs at 2 workgroups each
         hipLaunchKernelGGL((gemm_tile_kernel<4>), dim3(nblk128), dim3(256), 0, st, *g);
     } else {

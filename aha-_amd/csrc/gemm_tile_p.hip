@@ -103,7 +103,10 @@ static __device__ __forceinline__ void p288_epilogue(const GemmTileArgs& g, f32x
 #ifdef AHA_ABL_NOSTORE
             if (m < g.M && n < g.N && v[0] == (bf16)12345.0f) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;   // ablation build only
 #else
-            if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(g.C + (long)m * g.ldc + n) = v;
+            if (m < g.M && n < g.N) {
+                bf16* dst = g.ckb ? g.C + ((long)(n >> 5) * g.ckb + m) * 32 + (n & 31) : g.C + (long)m * g.ldc + n;   // k-blocked: the next GEMM's A
+                *reinterpret_cast<bf16x8*>(dst) = v;
+            }
 #endif
         }
     }
@@ -326,6 +329,8 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
     // registered at load): rows are 32 elements apart and a k-step N * 32, so the 16 rows of a piece are ONE contiguous KiB = 8 whole cache
     // lines instead of 16 half lines - the mid-M LM kernel's operands travel the same way (gemm_wl.hip, -16 % on down_proj).
     const unsigned wrs = g.Wkb ? 32u : (unsigned)g.ldw, wks = g.Wkb ? (unsigned)g.N * 32u : 32u;
+    // the same for A when its producer wrote it k-blocked [K/32][M][32] (g.akb = M: the tower's LayerNorm and fc1 epilogue at these shapes)
+    const unsigned ars = g.akb ? 32u : (unsigned)g.lda, aks = g.akb ? (unsigned)g.akb * 32u : 32u;
     int d_j = 0, d_k = 0;                                            // prefetch stream position: tile index, k-step
     auto set_tile_offsets = [&](int j) {
         int bm, bn;
@@ -336,10 +341,10 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
             const int wrow = (wave + 8 * i) * 16 + prow;             // swizzle key: (row >> 2) & 3 with the row index inside its operand
             poff[i] = (unsigned)min(n0 + wrow, g.N - 1) * wrs + ((pslot ^ ((wrow >> 2) & 3)) << 3);
             const int arow = (wave + 8 * i) * 16 + prow;
-            poff[2 + i] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((pslot ^ ((arow >> 2) & 3)) << 3);
+            poff[2 + i] = (unsigned)min(m0 + arow, g.M - 1) * ars + ((pslot ^ ((arow >> 2) & 3)) << 3);
         }
         const int arow = 256 + 4 * wave + qrow;
-        poff[4] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((qslot ^ ((arow >> 2) & 3)) << 3);
+        poff[4] = (unsigned)min(m0 + arow, g.M - 1) * ars + ((qslot ^ ((arow >> 2) & 3)) << 3);
     };
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Wb = reinterpret_cast<const char*>(g.Wkb ? g.Wkb : g.W);
@@ -349,9 +354,9 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
         if (i < 2)
             __builtin_amdgcn_global_load_lds((gptr_t)(Wb + ((size_t)poff[i] + (size_t)(k0 >> 5) * wks) * 2), (lptr_t)(sb + (PBM + (wave + 8 * i) * 16) * PBK), 16, 0, 0);
         else if (i < 4)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + ((wave + 8 * (i - 2)) * 16) * PBK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[i] + (size_t)(k0 >> 5) * aks) * 2), (lptr_t)(sb + ((wave + 8 * (i - 2)) * 16) * PBK), 16, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[4] + k0) * 2 + qbyte), (lptr_t)(sb + (256 + 4 * wave) * PBK), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[4] + (size_t)(k0 >> 5) * aks) * 2 + qbyte), (lptr_t)(sb + (256 + 4 * wave) * PBK), 4, 0, 0);
     };
     // advance the prefetch stream by one k-step (past the last real step it keeps re-reading the last one into dead stages:
     // the per-wave vmcnt arithmetic stays the same to the end)
@@ -559,6 +564,7 @@ extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g_, hipStream_t st)
         if (it != g_wkb_map.end() && it->second.N == gg.N && it->second.K == gg.K) gg.Wkb = it->second.kb;      // the whole matrix, as registered
     }
     const GemmTileArgs* g = &gg;
+    if ((gg.akb || gg.ckb) && (!g_p288_pipelined || (gg.akb && gg.akb != gg.M) || (gg.ckb && (gg.ckb != gg.M || (gg.N & 31))))) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_p288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);
