@@ -81,7 +81,6 @@ struct AttnArgs {
     // LM, frozen-static steps only: Q from the QKV GEMM's split-K slabs (null -> read a.q)
     const float* q_partial; int q_S; long q_slab_stride; int q_ldp;
     const bf16* q_bias; const bf16* rope_cos; const bf16* rope_sin; int n_pos;
-    WeightPrefetch pf;                                     // dense restaging kernel only: riders behind the row workgroups (n_riders = 0: none)
     int okb;                                               // LM mode: 0 = out row-major [B*T][ldo]; else k-blocked [ldo/32][okb rows][32] (consumer: the mid-M o_proj GEMM)
 };
 

@@ -42,14 +42,14 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
     const bool clip = d.v_kind == AHA_VISION_CLIP;
     const int Dv = d.v_hidden, T = c->Tt, rows = n * T, vhd = Dv / d.v_heads;
     const int act = clip ? ACT_QUICK_GELU : ACT_GELU_TANH;
-    // Latency path (a few frames): the tower's kernels are latency-bound chains with HBM almost idle (25 MB of weights per ~80 us layer), and
-    // every GEMM starts by waiting for its first weight tiles from HBM.  The attention launch of a layer (144 workgroups for ~12 us at one
-    // frame: most of the chip idle) therefore carries RIDERS - extra workgroups that only read bytes (prefetch_rider, aha_kernels.h) - for
-    // the weights used from two launches on: this layer's fc1 and fc2, the next layer's QKV and out-proj (after the last layer: the
-    // projector's two matrices, used by the encode calls right after the tower).  The first layer's QKV and out-proj weights ride on its
-    // LN1 launch.  With the weights in the Infinity Cache the one-frame encode measures 2.09 -> 1.9 ms (tools/diag/vit_prefetch.py; fully
-    // cache-resident weights, tuning "vit_alias": 1.74).  Riders change no output bit.  Tuning "vit_prefetch" = rows up to which it is on
-    // (0: off); the throughput path never prefetches (its GEMMs are not latency-bound and the riders would only take CUs).
+    // Latency path (a few frames): the tower's kernels are latency-bound chains with HBM almost idle (25 MB of weights per ~75 us layer), and
+    // every GEMM starts by waiting for its first weight tiles from HBM.  The two LayerNorm launches of a layer therefore carry RIDERS - extra
+    // workgroups that only read bytes (prefetch_rider, aha_kernels.h) - for weights used from two launches on: LN1 the layer's out-proj and
+    // fc1 weights, LN2 its fc2 weights and the next layer's QKV weights (after the last layer: the projector's first matrix, used by the
+    // encode calls right after the tower); the first layer's QKV weights ride on its own LN1.  With the weights in the Infinity Cache the
+    // one-frame encode measures 2.15 -> 1.88 ms (tools/diag/vit_prefetch.py; fully cache-resident weights, tuning "vit_alias": 1.74).
+    // Riders change no output bit.  Tuning "vit_prefetch" = rows up to which it is on (0: off); the throughput path never prefetches
+    // (its GEMMs are not latency-bound and the riders would only take CUs).
     const bool pf = rows <= c->vit_prefetch_rows && c->vit_riders > 0;
     // Throughput path: where the persistent tile kernel runs a GEMM (aha_gemm_tile_will_use_p288: from 8 frames of 576 patches up), its A
     // operand travels k-blocked [K/32][rows][32] - written that way by the producer (LayerNorm for QKV and fc1, fc1's epilogue for fc2) -
@@ -66,9 +66,9 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
         const auto vw = [&](int i) -> const VLayerW& { return c->V[c->vit_alias > 0 ? i % c->vit_alias : i]; };
         const VLayerW& w = vw(l);
         const bool last = l + 1 >= d.v_layers;
-        if (pf && l == l0) {
-            WeightPrefetch p0{{w.wqkv, w.wo, nullptr, nullptr}, {(long)b_qkv, (long)b_o, 0, 0}, c->vit_riders};
-            HIPCHK(c, aha_layernorm_pf(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, &p0, st));
+        if (pf) {
+            WeightPrefetch p1{{w.wo, w.w1, l == l0 ? w.wqkv : nullptr, nullptr}, {(long)b_o, (long)b_1, l == l0 ? (long)b_qkv : 0, 0}, c->vit_riders};
+            HIPCHK(c, aha_layernorm_pf(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, Dv, rows, Dv, d.v_ln_eps, &p1, st));
         } else if (kb_q)
             HIPCHK(c, aha_layernorm_kb(c->v_x, Dv, w.ln1w, w.ln1b, c->v_h, rows, Dv, d.v_ln_eps, st));
         else
@@ -87,21 +87,14 @@ int vit_layers(aha_ctx* c, int n, int l0, int l1, hipStream_t st) {
         a.T = T; a.G = 1; a.Hkv = d.v_heads; a.Lk = T;
         a.split_len = round_up(T, 64); a.n_splits = 1;
         a.scale = 1.0f / sqrtf((float)vhd);
-        if (pf) {
-            a.pf.p[0] = w.w1; a.pf.bytes[0] = (long)b_1;
-            a.pf.p[1] = w.w2; a.pf.bytes[1] = (long)b_2;
-            if (!last) {
-                a.pf.p[2] = vw(l + 1).wqkv; a.pf.bytes[2] = (long)b_qkv;
-                a.pf.p[3] = vw(l + 1).wo; a.pf.bytes[3] = (long)b_o;
-            } else if (c->p0w && c->p2w) {
-                a.pf.p[2] = c->p0w; a.pf.bytes[2] = (long)d.hidden * Dv * 2;
-                a.pf.p[3] = c->p2w; a.pf.bytes[3] = (long)d.hidden * d.hidden * 2;
-            }
-            a.pf.n_riders = c->vit_riders;
-        }
         HIPCHK(c, aha_attention(&a, nullptr, n, vhd, st));
         HIPCHK(c, tile_gemm(c->v_attn, Dv, rows, w.wo, Dv, Dv, Dv, c->v_x, Dv, w.bo, ACT_NONE, c->v_x, Dv, nullptr, 0, 0, st));
-        if (kb_1) HIPCHK(c, aha_layernorm_kb(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, rows, Dv, d.v_ln_eps, st));
+        if (pf) {
+            WeightPrefetch p2{{w.w2, nullptr, nullptr, nullptr}, {(long)b_2, 0, 0, 0}, c->vit_riders};
+            if (!last) { p2.p[1] = vw(l + 1).wqkv; p2.bytes[1] = (long)b_qkv; }
+            else if (c->p0w) { p2.p[1] = c->p0w; p2.bytes[1] = (long)d.hidden * Dv * 2; }
+            HIPCHK(c, aha_layernorm_pf(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, &p2, st));
+        } else if (kb_1) HIPCHK(c, aha_layernorm_kb(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, rows, Dv, d.v_ln_eps, st));
         else HIPCHK(c, aha_layernorm(c->v_x, Dv, w.ln2w, w.ln2b, c->v_h, Dv, rows, Dv, d.v_ln_eps, st));
         {
             GemmTileArgs g;

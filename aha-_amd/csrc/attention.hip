@@ -485,13 +485,6 @@ __global__ __launch_bounds__(256, (TPW == 1 && D <= 64) ? 4 : 1) void attn_dense
     using C = AttnCfg<D>;
     __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
     __shared__ __attribute__((aligned(16))) bf16 Vs[64 * C::VST];
-    // weight-prefetch riders (latency path, aha_kernels.h): the last a.pf.n_riders rows of grid.y of frame 0 only read bytes; with a
-    // single frame this launch covers 144 of the 256 CUs for ~12 us, so the riders run beside it for free
-    const int ny = (int)gridDim.y - a.pf.n_riders;
-    if ((int)blockIdx.y >= ny) {
-        if (blockIdx.z == 0) prefetch_rider(a.pf, (int)blockIdx.y - ny);
-        return;
-    }
     attn_dense_body<D, TPW>(a, blockIdx.y, blockIdx.z, Ks, Vs);
 }
 // Butterfly steps over lanes l ^ 16 and l ^ 32 on the vector ALU (v_permlane16_swap / v_permlane32_swap, gfx950) instead of
@@ -540,7 +533,7 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q4 = lane >> 4, r16 = lane & 15;
-    const int b = blockIdx.y, hk = blockIdx.x;
+    const int b = blockIdx.y, hk = blockIdx.x, rg = blockIdx.z;      // rg: row group of NW * TPW query tiles (latency path: several workgroups per head)
     const int R = a.G * a.T, RT = ceil_div(R, 16);
     const int Lk = a.Lk, ldk = a.ldk;
     const bf16* kb = a.k + b * a.kv_bs + hk * D;
@@ -566,7 +559,7 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
         }
     }
 
-    const int rt0 = wave * TPW;
+    const int rt0 = (rg * NW + wave) * TPW;
     const bool wave_on = rt0 < RT;
     bool row_ok[TPW];
     int trow[TPW], thead[TPW];
@@ -1066,10 +1059,7 @@ static int g_attn_lm = 1;        // tuning "attn_lm": attn_lm_kernel for frame-s
 extern "C" void aha_attention_set_lm_kernel(int v) { g_attn_lm = v; }
 
 template <int D>
-static hipError_t launch_attn(const AttnArgs& a_in, const StepDesc* sd_dev, int B, hipStream_t st) {
-    AttnArgs a = a_in;
-    const int riders = a.pf.n_riders > 0 && !sd_dev ? a.pf.n_riders : 0;      // weight-prefetch riders: dense restaging kernel, one tile per wave, only
-    a.pf.n_riders = 0;
+static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, hipStream_t st) {
     const int R = a.G * a.T, RT = ceil_div(R, 16), RG = ceil_div(RT, 4);
     dim3 grid(a.n_splits, a.Hkv * RG, B);
     if (sd_dev) {
@@ -1107,20 +1097,37 @@ static hipError_t launch_attn(const AttnArgs& a_in, const StepDesc* sd_dev, int 
         // barrier -> fragment reads -> MFMA -> softmax -> MFMA runs with little overlap at ~108 us.  Default: one tile per wave, the
         // same code path for every batch size; 128-wide heads do not fit more tiles in 256 VGPRs anyway.
         if constexpr (D == 64) {
-            // whole head LDS-resident (attn_head64_kernel): 64-wide heads whose K + V fit the CU's LDS and whose query rows fit
-            // 12 waves x 3 tiles; needs enough (frame, head) pairs to give every CU a workgroup (single-frame latency stays
-            // on the restaging kernel: 16 workgroups would leave the chip empty).  Tuning "attn_head": 0 off, 1 auto, 2 always.
+            // whole head LDS-resident (attn_head64_kernel): 64-wide heads whose K + V fit the CU's LDS.  Throughput path (>= 128 (frame, head)
+            // pairs: every CU gets a workgroup): one 12-wave workgroup per pair, three query tiles per wave.  [r5] Latency path (one to
+            // seven frames): 4-wave workgroups, each staging the head's K / V once (147 KB by LDS-DMA, ~2.5 us) and running its NW * TPW
+            // query tiles over all key blocks with no barrier - TPW the smallest of 1..3 that keeps the launch within one workgroup per CU.
+            // The restaging kernel it replaces there walks the 9 key blocks behind two barriers each: 12.2 us per layer at one frame.
+            // Same per-row arithmetic in every form: the choice (geometry only) cannot change a bit.  Tuning "attn_head": 0 off, 1 auto, 2
+            // the 12-wave form whenever eligible.
             const int lk_pad = round_up(a.Lk, 64), lds = 2 * lk_pad * 64 * 2;
-            if (g_attn_head && a.hd == 64 && lds <= 160 * 1024 - 1024 && RT <= 36 && a.Lk >= 64 &&
-                (g_attn_head == 2 || a.Hkv * B >= 128)) {
+            if (g_attn_head && a.hd == 64 && lds <= 160 * 1024 - 1024 && a.Lk >= 64) {
                 static bool attr_set = false;
                 if (!attr_set) {
                     hipError_t e = hipFuncSetAttribute((const void*)attn_head64_kernel<12, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_head64_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_head64_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_head64_kernel<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     if (e != hipSuccess) return e;
                     attr_set = true;
                 }
-                hipLaunchKernelGGL((attn_head64_kernel<12, 3>), dim3(a.Hkv, B), dim3(768), lds, st, a, lk_pad);
-                return hipGetLastError();
+                if (RT <= 36 && (g_attn_head == 2 || a.Hkv * B >= 128)) {
+                    hipLaunchKernelGGL((attn_head64_kernel<12, 3>), dim3(a.Hkv, B, 1), dim3(768), lds, st, a, lk_pad);
+                    return hipGetLastError();
+                }
+                if (g_attn_head == 1 && a.Hkv * B < 128) {
+                    int tpw = 1;
+                    while (tpw < 3 && (long)a.Hkv * B * ceil_div(RT, 4 * tpw) > 256) ++tpw;
+                    const dim3 grid(a.Hkv, B, ceil_div(RT, 4 * tpw));
+                    if (tpw == 1) hipLaunchKernelGGL((attn_head64_kernel<4, 1>), grid, dim3(256), lds, st, a, lk_pad);
+                    else if (tpw == 2) hipLaunchKernelGGL((attn_head64_kernel<4, 2>), grid, dim3(256), lds, st, a, lk_pad);
+                    else hipLaunchKernelGGL((attn_head64_kernel<4, 3>), grid, dim3(256), lds, st, a, lk_pad);
+                    return hipGetLastError();
+                }
             }
         }
         int tpw = g_dense_tpw == 0 ? 1 : g_dense_tpw;
@@ -1132,10 +1139,7 @@ static hipError_t launch_attn(const AttnArgs& a_in, const StepDesc* sd_dev, int 
             dim3 g(1, a.Hkv * ceil_div(RT, 8), B);
             hipLaunchKernelGGL((attn_dense_kernel<D, D <= 64 ? 2 : 1>), g, dim3(256), 0, st, a);
         } else {
-            // the one dense launch that honours weight-prefetch riders (aha_attention zeroes them for every other kernel)
-            AttnArgs ar = a;
-            ar.pf.n_riders = riders;
-            hipLaunchKernelGGL((attn_dense_kernel<D, 1>), dim3(grid.x, grid.y + riders, grid.z), dim3(256), 0, st, ar);
+            hipLaunchKernelGGL((attn_dense_kernel<D, 1>), grid, dim3(256), 0, st, a);
         }
     }
     return hipGetLastError();
@@ -1152,7 +1156,6 @@ extern "C" hipError_t aha_attention(const AttnArgs* a_, const StepDesc* sd, int 
     a.hd = head_dim;
     if (head_dim <= 64) return launch_attn<64>(a, sd, B, st);
     if (!sd && head_dim <= 96 && g_attn_d96) {
-        a.pf.n_riders = 0;
         // dense heads of 65..96 channels (so400m: 72): 3 QK^T k-steps and 6 output tiles instead of the 128-wide template's 4 and 8.
         // The padded channels are exact zeros in both templates, so a row's bits do not depend on which one ran.
         // Measured at 32 frames x 729 keys x 16 heads of 72: 279 -> 243 us per layer; two query tiles per wave: 306 us (worse).

@@ -35,7 +35,7 @@ for n in ns:
     fr = make_frames(n, cfg.vision.image_size, seed=0).cuda()
     rt.set_tuning("vit_prefetch", 0)
     ref = rt.visual_embed(fr).clone()
-    for rows, riders in ((0, 256), (2400, 256), (2400, 128), (2400, 512), (0, 256), (2400, 256), (2400, 384)):
+    for rows, riders in ((0, 256), (2400, 256), (2400, 128), (0, 256), (2400, 256)):
         rt.set_tuning("vit_prefetch", rows); rt.set_tuning("vit_riders", riders)
         same = torch.equal(rt.visual_embed(fr), ref)
         print(f"{n} frame(s) vit_prefetch={rows:4d} vit_riders={riders:3d}: {med(fr, True):.3f} ms (caches flushed)  {med(fr, False):.3f} ms (back to back)  bits {'same' if same else 'DIFFER'}", flush=True)
