@@ -1035,6 +1035,7 @@ static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t s
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
         case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
+        case 21: return launch_dma<3, 2, 2, 2, 3>(g, st);     //  96x64,  4 waves, 3 x 20 KB (2 per CU): fc1 of the latency path (M = 576: 384 tiles instead of 576)
         case 14: return launch_ps64(g, st);                      //  64x64, software-pipelined k-steps, 64 KB (2 per CU): the latency path
         case 12: return aha_gemm_tile_p288_ok(g) && g->wide_epi ? aha_gemm_tile_p288(g, st) : launch_dma32<4, 4, 4, 2, 3>(g, st);   // persistent 288x256 (gemm_tile_p.hip)
         default: return hipErrorInvalidValue;
@@ -1099,6 +1100,11 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
             // latency path (one or two frames): the narrow GEMMs (out-proj, fc2, patch embedding: N <= 1024) are <= 288 64x64 tiles,
             // one per CU, each a serial k-chain - the software-pipelined 64x64 kernel (M = 576: fc2 21.9 -> 16.4 us, out-proj 8.1 -> 6.6)
             if (v == 5 && g->N <= 1024 && g->M <= 1536) v = 14;
+            // ... and its widest GEMM (fc1: N = 4096, K = 1024) takes 96-row tiles when they divide M: a CU then ingests (96 + 64) rows of
+            // operands per 96 x 64 outputs instead of (64 + 64) per 64 x 64 - the latency path's GEMMs are bound by what a CU can take in
+            // by LDS-DMA.  Measured at M = 576: 14.2 -> 11.1 us (QKV at N = 3072 is faster on the 64 x 64 tiles: 10.2 vs 11.7; the 64 x 32 and
+            // 32 x 64 forms lose on every shape - profiles/r05_tile_sweep_latency_path.txt).
+            if (v == 5 && g->N >= 4096 && g->K <= 1024 && g->M <= 1152 && g->M % 96 == 0) v = 21;
         }
         return launch_dma_variant(v, g, st);
     }

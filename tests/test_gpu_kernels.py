@@ -145,7 +145,7 @@ def test_mid_m_gemm_kernel_is_bit_identical_to_the_register_streaming_kernel(op_
 # ---------------------------------------------------------------------------------------------------------------------
 # tiled MFMA GEMM (gemm_tile): the vision tower's and the projector's Linears
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", [0, 1, 11, 12, 14])
+@pytest.mark.parametrize("mode", [0, 1, 11, 12, 14, 21])
 def test_gemm_tile_within_one_ulp(op_rt, mode):
     _, _, rt = op_rt
     rt.set_tuning("tile_dma", mode)
