@@ -6,7 +6,7 @@
 #   sink_1stream_steady  1 stream, SinkCache W=2048: evicts + re-rotates + attends over 2,048 keys   tools/diag/sink_steps.py 1
 #   sink_8stream_steady  8 streams of the same                                         tools/diag/sink_steps.py 8
 # and one SQ/GRBM pass for MFMA utilisation on the vision tower (4 layers, 32 frames) and on the 8-stream LM step.
-# Output: gpurun_out/round/pmc_hbm_traffic.json, pmc_mfma_vit32.json, pmc_mfma_lm8.json   (copy into profiles/r04_*)
+# Output: gpurun_out/round/pmc_hbm_traffic.json, pmc_mfma_vit32.json, pmc_mfma_lm8.json   (copy into profiles/r05_*)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/round; mkdir -p $O; rm -rf $O/pmc_*
 cd /tmp && export TMPDIR=/tmp
 run() {   # tag counter(s) program args...
