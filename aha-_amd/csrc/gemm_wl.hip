@@ -27,8 +27,12 @@
 // (tests/test_gpu_parity.py::test_row_blocks_above_256_stay_bit_identical, test_full_size_batched_streams...).
 #include "aha_kernels.h"
 
+#ifndef AHA_WL_ABLATE
+#define AHA_WL_ABLATE 0        // diagnostic builds only (tools/diag/wl_ablate.sh): 1 no MFMA, 2 no result store, 4 no W DMA, 8 no X DMA
+#endif
 template <int MT, int WN, int EPI, int STAGES>
 __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
+    constexpr int ABL = AHA_WL_ABLATE;
     constexpr int NW = 2 * WN, NTB = 2 * WN, MH = MT / 2;          // waves, n-tiles per workgroup, row tiles per wave
     constexpr int NB = MT + NTB;                                    // 1-KiB blocks per stage: MT of X, then NTB of W
     constexpr int PX = (MT + NW - 1) / NW, P = PX + 1;              // DMA wave-instructions per wave per stage: PX X blocks + its one W block
@@ -69,10 +73,13 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
         const int ks = ks0 + min(kt, nk - 1);                       // past the end: refill a dead stage (keeps the vmcnt counts fixed)
         const long xk = min(ks, ksx_last) * xkstride;
         bf16* sa = lds + stage * STAGE;
+        if constexpr (!(ABL & 8)) {
 #pragma unroll
-        for (int i = 0; i < PX; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xk), (lptr_t)(sa + xblk[i] * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (long)ks * 512), (lptr_t)(sa + (MT + wave) * 512), 16, 0, 2);   // weights: read once, nontemporal
+            for (int i = 0; i < PX; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xk), (lptr_t)(sa + xblk[i] * 512), 16, 0, 0);
+        }
+        if constexpr (!(ABL & 4))
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (long)ks * 512), (lptr_t)(sa + (MT + wave) * 512), 16, 0, 2);   // weights: read once, nontemporal
     };
 
     f32x4 acc[MH][2];
@@ -103,10 +110,15 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
 #pragma unroll
             for (int i = 0; i < MH; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(lds + st_cur * STAGE + xoff + i * 512);
             __builtin_amdgcn_sched_barrier(0);                      // keep the reads ahead of the MFMAs (hipcc otherwise reads 2, waits, issues 4)
+            if constexpr (ABL & 1) {
 #pragma unroll
-            for (int i = 0; i < MH; ++i) {
-                acc[i][0] = mfma16(w0, xf[i], acc[i][0]);
-                acc[i][1] = mfma16(w1, xf[i], acc[i][1]);
+                for (int i = 0; i < MH; ++i) { acc[i][0][0] += (float)xf[i][0] * (float)w0[0]; acc[i][1][0] += (float)xf[i][1] * (float)w1[0]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MH; ++i) {
+                    acc[i][0] = mfma16(w0, xf[i], acc[i][0]);
+                    acc[i][1] = mfma16(w1, xf[i], acc[i][1]);
+                }
             }
             st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
             st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
@@ -116,6 +128,12 @@ __global__ __launch_bounds__(128 * WN) void gemm_wl_kernel(GemmWsArgs a) {
 
     // ---- epilogue (gemm_ws_body.h): acc[i][j][e] <-> row (wm*MH + i)*16 + r16, column (tile0 + j)*16 + q*4 + e
     if (tile0 >= a.n_tiles) return;
+    if constexpr (ABL & 2) {                                        // keeps the arithmetic alive, never stores
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MH; ++i) s += acc[i][0][0] + acc[i][0][1] + acc[i][0][2] + acc[i][0][3] + acc[i][1][0] + acc[i][1][1] + acc[i][1][2] + acc[i][1][3];
+        if (s != 12345.678f) return;
+    }
     if constexpr (EPI == EPI_PARTIAL) {
         float* base = a.partial + (long)blockIdx.y * a.slab_stride;
 #pragma unroll
