@@ -44,5 +44,28 @@ for n, T in ((32, 576), (9, 500), (64, 576)):
     n_bad = sum(int(not torch.equal(rt.vit_attention(qkv, 16, 64), ref)) for _ in range(rounds))
     total += rounds; bad += n_bad
     print(f"attn_head64 n={n} T={T}: {n_bad} of {rounds} launches differ", flush=True)
+# [r5] the latency path's row-group form of the head-resident kernel (4-wave workgroups, chosen automatically from one to seven frames)
+for n, T in ((1, 576), (2, 577), (4, 576), (7, 500)):
+    qkv = torch.randn(n, T, 3 * 1024, generator=g, device="cuda").bfloat16()
+    rt.set_tuning("attn_head", 0); ref = rt.vit_attention(qkv, 16, 64).clone()
+    rt.set_tuning("attn_head", 1)
+    n_bad = sum(int(not torch.equal(rt.vit_attention(qkv, 16, 64), ref)) for _ in range(rounds))
+    total += rounds; bad += n_bad
+    print(f"attn_head64 row groups n={n} T={T}: {n_bad} of {rounds} launches differ", flush=True)
+rt.close()
+# [r5] whole encodes: k-blocked weight twins and activations through the persistent tile kernel, LayerNorm launches carrying prefetch riders,
+# against the same tower with row-major operands, no riders and the restaging attention
+from aha_amd.config import LiveConfig, LMConfig
+from aha_amd.synth import make_frames
+cfg = LiveConfig(lm=LMConfig(num_hidden_layers=1, vocab_size=1024), name="vit24")
+rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True), max_step_tokens=64, max_vit_frames=32)
+for n in (32, 8, 1, 3):
+    fr = make_frames(n, cfg.vision.image_size, seed=n).cuda()
+    for k, v in (("tile_wkb", 0), ("vit_akb", 0), ("vit_prefetch", 0), ("attn_head", 0)): rt.set_tuning(k, v)
+    ref = rt.visual_embed(fr).clone()
+    for k, v in (("tile_wkb", 1), ("vit_akb", 1), ("vit_prefetch", 2400), ("attn_head", 1)): rt.set_tuning(k, v)
+    n_bad = sum(int(not torch.equal(rt.visual_embed(fr), ref)) for _ in range(rounds))
+    total += rounds; bad += n_bad
+    print(f"vision encode n={n} (k-blocked operands, riders, head-resident attention vs row-major, none, restaging): {n_bad} of {rounds} encodes differ", flush=True)
 print(f"RACE SCREEN: {bad} differing launches of {total}")
 sys.exit(1 if bad else 0)
