@@ -202,10 +202,13 @@ static __device__ __forceinline__ void wl_bal_body(const GemmWsArgs& a, bf16* ld
         const int ks = min(kt, KS - 1);
         const long xk = min(ks, ksx_last) * xkstride;
         bf16* sa = lds + stage * STAGE;
+        if constexpr (!(AHA_WL_ABLATE & 8)) {
 #pragma unroll
-        for (int i = 0; i < PX; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xk), (lptr_t)(sa + xblk[i] * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (long)ks * 512), (lptr_t)(sa + (MT + wave) * 512), 16, 0, 2);
+            for (int i = 0; i < PX; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + xk), (lptr_t)(sa + xblk[i] * 512), 16, 0, 0);
+        }
+        if constexpr (!(AHA_WL_ABLATE & 4))
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (long)ks * 512), (lptr_t)(sa + (MT + wave) * 512), 16, 0, 2);
     };
     f32x4 acc[NR][NP][2];
 #pragma unroll
@@ -231,13 +234,20 @@ static __device__ __forceinline__ void wl_bal_body(const GemmWsArgs& a, bf16* ld
 #pragma unroll
         for (int i = 0; i < NR; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + xoff + i * 512);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AHA_WL_ABLATE & 1) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
+            for (int i = 0; i < NR; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                acc[i][p][0] = mfma16(wf[p][0], xf[i], acc[i][p][0]);
-                acc[i][p][1] = mfma16(wf[p][1], xf[i], acc[i][p][1]);
-            }
+                for (int p = 0; p < NP; ++p) { acc[i][p][0][0] += (float)xf[i][0] * (float)wf[p][0][0]; acc[i][p][1][0] += (float)xf[i][1] * (float)wf[p][1][0]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    acc[i][p][0] = mfma16(wf[p][0], xf[i], acc[i][p][0]);
+                    acc[i][p][1] = mfma16(wf[p][1], xf[i], acc[i][p][1]);
+                }
+        }
         st_cur = st_cur == STAGES - 1 ? 0 : st_cur + 1;
         st_new = st_new == STAGES - 1 ? 0 : st_new + 1;
     }
