@@ -1100,6 +1100,14 @@ static hipError_t launch_attn(const AttnArgs& a, const StepDesc* sd_dev, int B, 
             }
         }
         hipLaunchKernelGGL((attn_fwd_kernel<D, true>), grid, dim3(256), 0, st, a, sd_dev);
+        if constexpr (D == 128) {
+            // more than one chunk of 16 splits (a one-stream cache of 4k-8k keys): the chunk-parallel merge, one memory round trip instead of
+            // two to four dependent ones (same arithmetic, same bits; 9.5 -> 7.9 us at 5,000 keys, 11.1 -> 8.2 at 6,500)
+            if (a.n_splits > 16 && a.hd == D) {
+                hipLaunchKernelGGL((attn_combine16c_kernel<D>), dim3(ceil_div(R, 4), a.Hkv, B), dim3(256), 0, st, a, sd_dev);
+                return hipGetLastError();
+            }
+        }
         if (a.n_splits > 1)
             hipLaunchKernelGGL((attn_combine_kernel<D>), dim3(R, a.Hkv, B), dim3(D), 0, st, a, sd_dev);
     } else {
