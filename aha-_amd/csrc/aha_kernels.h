@@ -93,6 +93,34 @@ struct ResidNormArgs {
     int xkb;                         // 0: xn row-major [M][ldx]; else k-blocked [H/32][xkb rows][32] (consumer: the mid-M GEMM)
 };
 
+// ---- the persistent layer engine (lm_engine.hip): GEMM phases over an LDS-DMA weight ring, hand-offs through counters
+struct EngGemm {
+    const bf16x8* Wp; int KS;        // packed weight (gemm_ws.hip layout) and its k-steps per n-tile
+    const bf16* Xkb;                 // input panels [KS][48][32] (k-blocked, 48-row panels; rows >= M and k-steps >= K/32 are zero)
+    int epi;                         // EPI_SWIGLU: gate/up pairs -> out_kb (write-through) + per-slice "pairs done" counters; EPI_PARTIAL: split-K slabs
+    bf16* out_kb; int out_cols;      // EPI_SWIGLU: activation panels [out_cols/32][48][32]
+    float* partial; int ldp; long slab_stride;   // EPI_PARTIAL: slab s at partial + s*slab_stride, rows [M][ldp]
+};
+struct EngAssign {                   // what ONE workgroup does in ONE GEMM phase (host-built table, [phase][workgroup])
+    int tile0, nt;                   // its n-tiles [tile0, tile0 + nt), nt <= 10
+    int ks0, nk;                     // its k-steps [ks0, ks0 + nk), nk even
+    int slice;                       // EPI_PARTIAL: the slab it writes
+    int ready_idx, ready_target;     // its X panels are published when sync[ready_idx*32] >= ready_target
+    int sig0_idx, sig0_cnt, sig1_idx, sig1_cnt;   // EPI_SWIGLU: counters it adds to when its outputs are stored
+    int pad_;
+};
+struct EngArgs {
+    ResidNormArgs rn;                // row phase: workgroup r < M reduces row r (rn.xn = 48-row panels, written write-through); rn.H = 0: none
+    int rows_idx;                    // counter the row phase adds to (one per finished row)
+    int M, grid, n_gemm;
+    EngGemm gemm[4];
+    const EngAssign* asg;            // [n_gemm][grid]
+    unsigned* sync;                  // this launch's counters, one per 128-byte line, zeroed before the step
+    int* err;                        // sticky device error word (heads_kernel poisons the scores when set)
+    unsigned long long* stamps;      // diagnostic: [grid][16] wall-clock stamps (null in the product)
+    int exp;                         // experiment bits (tuning "engine_exp")
+};
+
 // frame ingest (ingest.hip): one source frame -> one [3,S,S] canvas
 struct IngestArgs {
     const uint8_t* src; int h, w, src_bgr;       // uint8 [h][w][3]; src_bgr: channels arrive B,G,R
@@ -138,6 +166,10 @@ void aha_attention_set_head_kernel(int v);
 void aha_attention_set_d96(int v);
 extern "C" void aha_gemm_wl_set_balanced(int on);
 hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd_dev, int B, int head_dim, hipStream_t st);   // sd_dev: DEVICE pointer or null (dense)
+hipError_t aha_lm_engine(const EngArgs* a, hipStream_t st);
+int aha_lm_engine_lds_bytes();
+int aha_lm_engine_rows();
+int aha_lm_engine_ntmax();
 hipError_t aha_rmsnorm(const bf16* x, int ldx, const bf16* w, bf16* out, int ldo, int M, int H, float eps, hipStream_t st);
 hipError_t aha_resid_norm(const ResidNormArgs* a, int M, hipStream_t st);
 hipError_t aha_qkv_finish(const QkvFinishArgs* a, const StepDesc* sd_dev, int M, hipStream_t st);   // sd_dev: DEVICE pointer
@@ -156,6 +188,7 @@ hipError_t aha_layernorm_pf(const bf16* x, int ldx, const bf16* w, const bf16* b
 hipError_t aha_layernorm_kb(const bf16* x, int ldx, const bf16* w, const bf16* b, bf16* out_kb, int M, int D, float eps, hipStream_t st);   // out k-blocked [D/32][M][32]
 hipError_t aha_pool(const bf16* in, bf16* out, int N, int g, int go, int H, int stride, int mode, int frame_rows, hipStream_t st);
 hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st);
+hipError_t aha_kblocked_to_rows_n(const bf16* in, int M, int rows, int K, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go, int s, int Dv, int frame_rows, hipStream_t st);
 hipError_t aha_embed_gather(const long* ids, int n, const bf16* table, int H, int vocab, bf16* out, int ldo, hipStream_t st);
 hipError_t aha_argmax(const float* logits, int ld, int V, int rows, long* out, hipStream_t st);

@@ -119,6 +119,18 @@ struct aha_ctx {
     int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
+    // persistent layer engine (lm_engine.hip; tuning "engine": 0 off (default), 1 = single-stream steps (M <= 48 rows) run the MLP half of
+    // every layer - post-attention resid_norm, gate/up + SwiGLU, down_proj - as one persistent launch).  Bit-identical; measured 5 % SLOWER
+    // than the three launches on the whole step (profiles/r06_engine_mlp_stamps.txt), so it is an experiment, not the product path.
+    int engine = 0;
+    bf16 *eng_xn = nullptr, *eng_act = nullptr;             // hand-off panels [K/32][48][32]
+    unsigned* eng_sync = nullptr;                           // [layers][16 counters, one per 128-byte line], zeroed once per step
+    EngAssign* eng_asg = nullptr;                           // device copy of eng_host
+    std::vector<EngAssign> eng_host;                        // [phase][workgroup]
+    int eng_epoch = -1, eng_grid = 0, eng_G = 0; bool eng_ok = false;
+    unsigned long long* eng_stamps = nullptr;               // diagnostic (aha_lm_engine_stamps)
+    int eng_exp = 0;                                        // tuning "engine_exp": experiment bits handed to the kernel
+    int eng_ran = 0;                                        // rows of the last step if the engine produced c->eng_act (parity tap 4), else 0
     // accounting of the last step
     double last_weight_bytes = 0, last_kv_bytes = 0, last_flops = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GK_COUNT];

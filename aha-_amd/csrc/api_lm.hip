@@ -132,6 +132,56 @@ void attn_geometry(const aha_ctx* c, int B, int T, int max_lk, int split_overrid
     *n_splits_out = n_splits;
 }
 
+// --------------------------------------------------------------------------------------------
+// Persistent layer engine (lm_engine.hip): who does what.  The chip is G = split_down groups of CPG workgroups (workgroup w: group
+// w % G, member w / G).  Group g owns down_proj's K slice g - the slices are gemm_ws_kernel's, in units of 8 k-steps - its members
+// split the slice's n-tiles, and they also compute the gate/up column pairs that make up that slice of the activation, so the
+// hand-off's producers and consumers are the same 32 CUs.  The table depends on the shapes and the split tuning only; it is rebuilt
+// (one blocking upload) when a tuning changed.  Returns false when the shape does not fit the engine (the launches run instead).
+// --------------------------------------------------------------------------------------------
+bool eng_prepare(aha_ctx* c) {
+    if (c->eng_epoch == c->tune_epoch) return c->eng_ok;
+    c->eng_epoch = c->tune_epoch;
+    c->eng_ok = false;
+    const aha_model_desc& d = c->d;
+    if (c->L.empty()) return false;
+    const PackedW& gu = c->L[0].gateup; const PackedW& dn = c->L[0].down;
+    const int grid = c->n_cus, G = pick_split(c, GK_DOWN, dn, 36, 1), ROWS = aha_lm_engine_rows(), NTMAX = aha_lm_engine_ntmax();
+    if (grid < 8 || G < 1 || grid % G) return false;
+    const int CPG = grid / G, H = d.hidden, I = d.inter;
+    if ((H >> 3) > 8 * 64 || H % 32 || I % 32) return false;                 // the row phase keeps <= 2 chunks per lane on 4 waves
+    if (gu.KS * 32 < H || dn.KS * 32 < I || (gu.n_tiles & 1) || dn.KS % 8) return false;
+    const int pairs_total = gu.n_tiles / 2, NC8 = dn.KS / 8;
+    std::vector<EngAssign> t((size_t)2 * grid);
+    memset(t.data(), 0, t.size() * sizeof(EngAssign));
+    for (int w = 0; w < grid; ++w) {
+        const int g = w % G, i = w / G;
+        const int ks0 = (int)(((long)g * NC8) / G) * 8, ks1 = (int)(((long)(g + 1) * NC8) / G) * 8;
+        const int pb = std::min(2 * ks0, pairs_total), pe = std::min(2 * ks1, pairs_total), np = pe - pb;   // a k-step of down = 32 activation columns = 2 pairs
+        const int p0 = pb + (int)(((long)i * np) / CPG), p1 = pb + (int)(((long)(i + 1) * np) / CPG);
+        EngAssign& a = t[w];                                                 // phase 0: gate/up + SwiGLU
+        a.tile0 = 2 * p0; a.nt = 2 * (p1 - p0); a.ks0 = 0; a.nk = a.nt ? gu.KS : 0; a.slice = 0;
+        a.ready_idx = 0; a.ready_target = -1;                               // the row phase: all M rows normalised
+        a.sig0_idx = 1 + g; a.sig0_cnt = p1 - p0;
+        EngAssign& b = t[(size_t)grid + w];                                  // phase 1: down_proj, K slice g
+        const int t0 = (int)(((long)i * dn.n_tiles) / CPG), t1 = (int)(((long)(i + 1) * dn.n_tiles) / CPG);
+        b.tile0 = t0; b.nt = t1 - t0; b.ks0 = ks0; b.nk = b.nt ? ks1 - ks0 : 0; b.slice = g;
+        b.ready_idx = 1 + g; b.ready_target = np;
+        if (a.nt > NTMAX || b.nt > NTMAX || (a.nk & 1) || (b.nk & 1)) return false;
+    }
+    if (1 + G > 15) return false;
+    if (!c->eng_xn) {
+        const size_t nx = (size_t)gu.KS * ROWS * 32, na = (size_t)dn.KS * ROWS * 32, ns = (size_t)d.layers * 512;
+        if (dalloc(c, &c->eng_xn, nx) || dalloc(c, &c->eng_act, na) || dalloc(c, &c->eng_sync, ns) || dalloc(c, &c->eng_asg, t.size())) return false;
+        // pad rows (>= M) and pad k-steps (>= K/32) of the panels are never written: they must be finite (they meet real weights / zero weights)
+        if (hipMemset(c->eng_xn, 0, nx * 2) != hipSuccess || hipMemset(c->eng_act, 0, na * 2) != hipSuccess || hipMemset(c->eng_sync, 0, ns * 4) != hipSuccess) return false;
+    } else if (grid != c->eng_grid) return false;
+    c->eng_host = t;
+    if (hipMemcpy(c->eng_asg, c->eng_host.data(), t.size() * sizeof(EngAssign), hipMemcpyHostToDevice) != hipSuccess) return false;
+    c->eng_grid = grid; c->eng_G = G; c->eng_ok = true;
+    return true;
+}
+
 extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const void* embeds, int T, float* out_scores,
                            float* out_raw, void* out_last_hidden, aha_hip_stream st_) {
     if (!c || !streams || !embeds) return AHA_E_INVAL;
@@ -270,7 +320,11 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     const bool qkv_kb = c->act_kb >= 3 && H % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, H);
     const bool o_kb = c->act_kb >= 3 && QD % 32 == 0 && Dh % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, QD) && !static_attn && !frozen_all;
     c->attn_kb_rows = o_kb ? M : 0;
+    // single-stream steps: the MLP half of every layer as one persistent launch (lm_engine.hip); same bits as the launches
+    const bool use_eng = c->engine && M <= aha_lm_engine_rows() && !c->time_gemm && pick_split(c, GK_O, c->L[0].o, M, 1) <= 8 && eng_prepare(c) && pick_split(c, GK_DOWN, c->L[0].down, M, 1) == c->eng_G;
+    c->eng_ran = use_eng ? M : 0;
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
+        if (use_eng) HIPCHK(c, hipMemsetAsync(c->eng_sync, 0, (size_t)d.layers * 512 * sizeof(unsigned), st));
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
 
@@ -335,7 +389,20 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
             ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
             const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
-            {
+            if (use_eng) {
+                EngArgs ea;
+                memset(&ea, 0, sizeof(ea));
+                ea.rn = ra; ea.rn.xn = c->eng_xn; ea.rows_idx = 0;
+                ea.M = M; ea.grid = c->eng_grid; ea.n_gemm = 2;
+                ea.gemm[0].Wp = w.gateup.p; ea.gemm[0].KS = w.gateup.KS; ea.gemm[0].Xkb = c->eng_xn; ea.gemm[0].epi = EPI_SWIGLU;
+                ea.gemm[0].out_kb = c->eng_act; ea.gemm[0].out_cols = I;
+                ea.gemm[1].Wp = w.down.p; ea.gemm[1].KS = w.down.KS; ea.gemm[1].Xkb = c->eng_act; ea.gemm[1].epi = EPI_PARTIAL;
+                ea.gemm[1].partial = c->partial; ea.gemm[1].ldp = H; ea.gemm[1].slab_stride = (long)M * H;
+                ea.asg = c->eng_asg; ea.sync = c->eng_sync + (size_t)l * 512; ea.err = c->bar_err; ea.stamps = c->eng_stamps; ea.exp = c->eng_exp;
+                HIPCHK(c, aha_lm_engine(&ea, st));
+                c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
+                c->last_flops += 2.0 * ((double)w.gateup.n_tiles * 16.0 * w.gateup.K + (double)w.down.n_tiles * 16.0 * w.down.K) * (double)M;
+            } else {
                 // Between mid-M kernels the operands travel k-blocked ([K/32][M][32]): the consumer's LDS-DMA then pulls
                 // contiguous 1-KiB panels instead of 16 half cache lines per instruction (-16 % on down at M = 288; same bits).
                 // Here: the normed input of gate/up (xkb) and the SwiGLU activation for down_proj (akb).
@@ -376,10 +443,10 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     for (int b = 0; b < B; ++b)
         if (sd.s[b].write_base >= 0 && guard.saved[b][0] + sd.s[b].write_count > sd.s[b].len_after) guard.destructive = true;
     const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
-    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0);
+    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0) | (use_eng ? 8 : 0);
     // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
     // does not become a graph node, so a replay would leave the events holding stale timestamps.)
-    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->time_gemm) {
+    if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->time_gemm && !c->eng_stamps) {
         aha_ctx::GraphEntry* ge = nullptr;
         for (auto& g : c->graphs)
             if (g.B == B && g.T == T && g.epoch == c->tune_epoch && g.n_splits == n_splits && g.split_len == split_len && g.flags == gflags) {
@@ -500,6 +567,10 @@ extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream
             }
             src = c->attn_out; cols = (size_t)c->d.heads * c->d.head_dim; break;
         case 4:
+            if (c->eng_ran) {                                      // the layer engine leaves the activation in its 48-row panels
+                HIPCHK(c, aha_kblocked_to_rows_n(c->eng_act, aha_lm_engine_rows(), c->eng_ran, c->d.inter, (bf16*)out, c->d.inter, st));
+                return 0;
+            }
             if (c->act_kb_rows) {                                  // the mid-M path leaves the activation k-blocked
                 HIPCHK(c, aha_kblocked_to_rows(c->act, c->act_kb_rows, c->d.inter, (bf16*)out, c->d.inter, st));
                 return 0;
@@ -508,6 +579,12 @@ extern "C" int aha_lm_debug_tap(aha_ctx* c, int which, void* out, aha_hip_stream
         default: return fail(c, AHA_E_INVAL, "unknown tap");
     }
     HIPCHK(c, hipMemcpyAsync(out, src, M * cols * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int aha_lm_engine_stamps(aha_ctx* c, void* stamps) {
+    if (!c) return AHA_E_INVAL;
+    c->eng_stamps = (unsigned long long*)stamps;
     return 0;
 }
 

@@ -884,20 +884,22 @@ hipError_t aha_gather_pool_rows(const bf16* in, bf16* out, int N, int g, int go,
     return hipGetLastError();
 }
 // k-blocked [K/32][M][32] -> row-major [M][ldo] (parity taps of the mid-M path; 16 B per thread)
-__global__ void kblocked_to_rows_kernel(const bf16* __restrict__ in, int M, int K, bf16* __restrict__ out, int ldo) {
+__global__ void kblocked_to_rows_kernel(const bf16* __restrict__ in, int M, int rows, int K, bf16* __restrict__ out, int ldo) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece
     if (i >= (long)M * (K >> 3)) return;
     const int c = (int)(i & 3);
     const long rk = i >> 2;
     const int row = (int)(rk % M), kt = (int)(rk / M);
-    *reinterpret_cast<bf16x8*>(out + (long)row * ldo + kt * 32 + c * 8) = *reinterpret_cast<const bf16x8*>(in + i * 8);
+    if (row < rows) *reinterpret_cast<bf16x8*>(out + (long)row * ldo + kt * 32 + c * 8) = *reinterpret_cast<const bf16x8*>(in + i * 8);
 }
-hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st) {
+// panels of M rows, of which the first `rows` are copied out (the layer engine's hand-off panels are 48 rows high whatever the step's M)
+hipError_t aha_kblocked_to_rows_n(const bf16* in, int M, int rows, int K, bf16* out, int ldo, hipStream_t st) {
     if (K % 32 || ldo % 8) return hipErrorInvalidValue;
     const long total = (long)M * (K >> 3);
-    hipLaunchKernelGGL(kblocked_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, M, K, out, ldo);
+    hipLaunchKernelGGL(kblocked_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, M, rows, K, out, ldo);
     return hipGetLastError();
 }
+hipError_t aha_kblocked_to_rows(const bf16* in, int M, int K, bf16* out, int ldo, hipStream_t st) { return aha_kblocked_to_rows_n(in, M, M, K, out, ldo, st); }
 // row-major [rows][ld] (first K columns, K % 32 == 0) -> k-blocked [K/32][rows][32]: what an LDS-DMA piece of 16 rows x 64 B then reads is
 // one contiguous KiB instead of sixteen half cache lines (tile-GEMM weights: gemm_tile_p.hip)
 __global__ void rows_to_kblocked_kernel(const bf16* __restrict__ in, int rows, int K, int ld, bf16* __restrict__ out) {

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("aha_pool_forward", _I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     ("aha_pool_gather_rows_forward", _I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     ("aha_lm_debug_tap", _I, [_P, _I, _P, _P]),
+    ("aha_lm_engine_stamps", _I, [_P, _P]),
     ("aha_comm_unique_id", _I, [_P, C.c_size_t]),
     ("aha_comm_init_rank", _I, [_P, C.c_size_t, _I, _I, _I, C.POINTER(_P)]),
     ("aha_comm_size", _I, [_P]),

@@ -106,6 +106,9 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *                     directly, not replayed from a graph, so the events are live
  *   "pool_subset"     1 (default): the projector runs only on the patch rows that bilinear pooling with an even integer stride samples
  *                     (24 -> 6: 144 of 576 per frame); bit-identical embeddings
+ *   "engine"          1: single-stream steps (<= 48 rows) run each layer's MLP half - post-attention resid_norm, gate/up + SwiGLU,
+ *                     down_proj - as ONE persistent launch on an LDS-DMA weight ring (lm_engine.hip); bit-identical to the launches;
+ *                     0 (default): the launches (the engine measured slower: profiles/r06_engine_mlp_stamps.txt)
  *   "static_attn"     1 (default): frozen TrulyStaticCache steps whose prefix is <= 64 keys run qkv_finish + attention as one launch
  *   "attn_lm"         LM attention kernel for frame-sized steps: 0 attn_fwd_kernel always, 1 auto (default), 2 attn_lm_kernel always
  *   "use_wl"          1 (default): row chunks above 128 use the mid-M GEMM kernel (both operands staged through LDS); 0: never.
@@ -291,6 +294,13 @@ int aha_lm_last_step_work(aha_ctx* ctx, double* weight_bytes, double* kv_bytes, 
  * re-rotation.  Returns summed ms, launch-group count and the ALGORITHMIC bytes of those launches (packed weight bytes
  * streamed; K+V bytes read; kept keys read + written).  Synchronises on the recorded events. */
 int aha_lm_last_gemm_time(aha_ctx* ctx, int kind, float* ms, int* launches, double* gemm_weight_bytes);
+/* Diagnostic of the persistent layer engine (tuning "engine"; the launch that replaces the post-attention resid_norm, gate/up and
+ * down_proj launches of a single-stream step - the MLP of the decoder layer /root/reference/test/inference.py:217 runs): `stamps`
+ * = device buffer of [CUs][16] uint64, or null to stop.  While set, every engine launch overwrites it with 100-MHz wall-clock
+ * stamps per workgroup (0 loader start, 1/2 last weight slot of gate/up / down issued, 3 loader drained, 4/5 gate/up's / down's
+ * input published, 6/7/8 gate/up first slot in hand / last slot consumed / activation published, 9/10 the same for down,
+ * 12 row normalised, 13 workgroup done); graph replay is bypassed for such steps. */
+int aha_lm_engine_stamps(aha_ctx* ctx, void* stamps);
 const char* aha_version(void);
 
 /* ---- vision operators: the tower's non-GEMM kernels on caller tensors (its GEMMs are aha_linear_tile_forward).  The parity

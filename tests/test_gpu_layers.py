@@ -191,6 +191,35 @@ def test_tail_final_norm_and_heads_flat_bounds_and_score_fraction(full):
     assert d_hip.mean().item() <= max(1e-3, 2.0 * d_ref.mean().item()), (d_hip.mean().item(), d_ref.mean().item())
 
 
+def test_layer_engine_gives_the_bits_of_the_launches_it_replaces(full):
+    """The persistent MLP-half launch (lm_engine.hip, tuning "engine"; opt-in since it measured slower) against the three launches: same
+    slab sums, same k-step order, same roundings -> every tap, the heads and the scores bit for bit, 28 layers deep, for a frame
+    (36 rows), a single token and a full 48-row step, also when replayed from a captured graph."""
+    cfg, rt, _ob, _w = full
+    H = cfg.lm.hidden_size
+    g = torch.Generator(device="cuda").manual_seed(11)
+    st = rt.open_stream("static", 2048, 32)
+    rt.lm_step([st], (torch.randn(1, 20, H, generator=g, device="cuda") * 0.05).bfloat16())
+    try:
+        for T in (36, 1, 48):
+            x = (torch.randn(1, T, H, generator=g, device="cuda") * 0.05).bfloat16()
+            outs = {}
+            for lv in (0, 1):
+                rt.set_tuning("engine", lv)
+                sc, raw, hid = rt.lm_step([st], x, want_raw=True, want_hidden=True)
+                outs[lv] = {"scores": sc.clone(), "raw": raw.clone(), "hid": hid.clone()}
+                for name in ("h", "xn", "act"):
+                    outs[lv][name] = rt.debug_tap(name, 1, T).clone()
+                replay = [rt.lm_step([st], x).clone() for _ in range(3)]           # the third call runs the captured graph
+                outs[lv]["replay"] = replay[-1]
+                assert torch.equal(replay[0], replay[-1])
+            for k in outs[0]:
+                assert not torch.isnan(outs[1][k].float()).any(), (T, k)
+                assert torch.equal(outs[0][k], outs[1][k]), f"T={T} {k}: engine differs from the launches"
+    finally:
+        rt.set_tuning("engine", 0)
+
+
 def _oracle_last_layer(ob, x_in, l):
     """The oracle's decoder layer l alone on an empty cache, then model.norm and the heads (same torch calls as OracleLM.step)."""
     import torch.nn.functional as F
