@@ -32,13 +32,24 @@ class _BoundCache:
         """Cache.update of the reference: append this layer's new (already rotated) keys / values, bf16 [1, kv_heads, T,
         head_dim], evicting / re-rotating as the policy says, and return the (K, V) the attention must see, [1, kv_heads, L,
         head_dim].  As in the reference the layer_idx == 0 call advances the bookkeeping (seen tokens, eviction) and the other
-        layers of the step follow in order.  `cache_kwargs` ("sin", "cos", "cache_position", ...) is accepted and ignored: the
-        re-rotation coefficients come from the runtime's own RoPE table (bit-identical to SinkCache's, test/sink_cache.py:35-55)."""
+        layers of the step follow in order.
+
+        `cache_kwargs` (test/sink_cache.py:100-103): the re-rotation coefficients come from the runtime's own RoPE table (bit-identical
+        to what SinkCache accumulates from the "cos" / "sin" it is handed, test/sink_cache.py:35-55,109-121), so the tensors are only
+        CHECKED, on the layer-0 call, against that table at the positions get_seq_length() + arange(T) - the only positions the
+        reference's callers pass.  Where the reference would behave differently from this ring the call is refused, loudly, before
+        anything changes: SinkCache without cos / sin (the reference then shifts the kept keys WITHOUT re-rotating them), a
+        `partial_rotation_size`, or cos / sin of other positions.  SlidingWindowCache / TrulyStaticCache ignore the kwargs, as the
+        reference's do."""
         if self.stream is None:
             raise RuntimeError("cache is not bound to a runtime: call cache.bind(runtime) (or hand it to LiveLlavaModel) first")
         if key_states.dim() == 4 and key_states.shape[0] != 1:
             raise ValueError("one stream per cache object: batch dimension must be 1")
+        self._check_kwargs(key_states, int(layer_idx), cache_kwargs)
         return self.stream.rt.cache_update(self.stream, int(layer_idx), key_states, value_states)
+
+    def _check_kwargs(self, key_states, layer_idx: int, cache_kwargs) -> None:
+        pass
 
     def get_max_length(self) -> Optional[int]:
         return self.window_length
@@ -62,6 +73,17 @@ class SinkCache(_BoundCache):
     def __init__(self, window_length: int, num_sink_tokens: int) -> None:
         super().__init__()
         self.window_length, self.num_sink_tokens = window_length, num_sink_tokens
+
+    def _check_kwargs(self, key_states, layer_idx: int, cache_kwargs) -> None:
+        kw = cache_kwargs or {}
+        if kw.get("partial_rotation_size") is not None:
+            raise NotImplementedError("SinkCache.update: partial_rotation_size is not supported (Qwen2 rotates the whole head_dim)")
+        cos, sin = kw.get("cos"), kw.get("sin")
+        if cos is None or sin is None:
+            raise ValueError("SinkCache.update needs cache_kwargs['cos'] and ['sin'] (test/sink_cache.py:100-103): without them the "
+                             "reference shifts the kept keys without re-rotating them, which this ring does not do")
+        if layer_idx == 0:
+            self.stream.rt.check_rope_rows(cos, sin, self.stream.get_seq_length(), key_states.shape[-2])
 
 
 class SlidingWindowCache(_BoundCache):

@@ -151,7 +151,6 @@ hipError_t aha_gemm_tile(const GemmTileArgs* g, hipStream_t st);
 void aha_gemm_tile_set_dma(int on);
 void aha_gemm_tile_set_epi(int on);
 void aha_gemm_tile_set_p288(int on);
-void aha_gemm_tile_p288_set_pipelined(int v);
 hipError_t aha_gemm_tile_p288(const GemmTileArgs* g, hipStream_t st);
 int aha_gemm_tile_will_use_p288(const GemmTileArgs* g);     // 1: aha_gemm_tile would run this shape on the persistent 288x256 kernel (the only one that takes akb / ckb)
 void aha_gemm_tile_kb_register(const void* w_rowmajor, const void* w_kblocked, int N, int K);   // k-blocked twin of a tile-GEMM weight (gemm_tile_p.hip); null twin: forget

@@ -153,7 +153,6 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "attn_d96") aha_attention_set_d96(value);             // 96-wide dense attention template for head dims 65..96: 0 pads to 128
     else if (k == "attn_tpw") aha_attention_set_dense_tpw(value);   // dense attention: query tiles per wave (0 auto)
     else if (k == "tile_dma") aha_gemm_tile_set_dma(value);
-    else if (k == "tile_p288s") aha_gemm_tile_p288_set_pipelined(value);   // 1 (default): software-pipelined fragment reads in the persistent tile kernel
     else if (k == "tile_p288") aha_gemm_tile_set_p288(value);    // 1 (default): persistent 288x256 tile kernel on the throughput shapes
     else if (k == "tile_wkb") aha_gemm_tile_set_wkb(value);      // 1 (default): the persistent tile kernel reads registered weights from their k-blocked twins
     else if (k == "tile_epi") aha_gemm_tile_set_epi(value);      // 1 (default): LDS-transposed wide epilogue of the LDS-DMA tile kernels      // 0 off, 1 auto (default), 2 force

@@ -805,199 +805,6 @@ static hipError_t launch_dma32(const GemmTileArgs* g, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256x256x64 tile, 8 waves as 2(M) x 4(N), each wave 128x64 = 8x4 accumulator tiles (128 VGPRs).  Half the operand
-// bytes per flop of the 256x128 tile, which is what caps that one (a CU ingests only ~35-55 GB/s by LDS-DMA).
-// A k-tile is staged as four 16 KB half-tiles - A0/A1 = the rows of every wave's upper/lower 64-row half, W0/W1 = the
-// columns of every wave's left/right 32-column half - in two buffers (128 KB).  A k-tile is computed in four quadrant
-// phases (m-half, n-half) = (0,0) (0,1) (1,1) (1,0), 16 MFMAs each; fragments shared by consecutive phases stay in
-// registers.  Each phase issues ONE half-tile (2 LDS-DMA pieces per thread) into a slot whose last reader phase is
-// behind a barrier already:
-//     p0 (0,0): read A0,W0 | issue W0(kt+1)        p2 (1,1): read A1    | issue A0(kt+2)
-//     p1 (0,1): read W1    | issue A1(kt+1), then vmcnt(8): A1(kt) landed        (read in p2)
-//     p3 (1,0): read W0    | issue W1(kt+2), then vmcnt(6): A0,W1,W0(kt+1) landed (read in p0/p1 of the next tile)
-// so every half-tile has 4-6 phases (one k-tile of MFMA time or more) to arrive and ~5 half-tiles (80 KB) are in flight;
-// issue order is A0(t) W1(t) W0(t) A1(t) for t = 0,1,2..., which makes both waits constant counts.  One raw s_barrier
-// per phase orders both hazards (wait -> barrier -> read; read -> barrier -> refill).  Accumulation order per output
-// element is the same sequential k order as every other variant: bit-identical results.
-// MEASURED (profiles/r01_gemm_tile_256_sweep.txt): it ingests ~35 GB/s per CU like the 256x128 tile, i.e. 1.8 us per
-// k-tile ~ 1.2 PF at best, but on the tower's shapes (K = 1024 -> 16 k-tiles per tile; 288-1152 tiles on 256 CUs) the
-// longer prologue/epilogue and the round quantisation cost more than that: 213 vs 157 us (QKV), 265 vs 202 us (fc1) at
-// 32 frames.  Not selected automatically; variant 7 for sweeps and for long-K / well-quantised shapes.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gemm_tile_256_kernel(GemmTileArgs g) {
-    constexpr int HALF = 128 * TBK;                                 // elements per half-tile (16 KB)
-    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
-    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);                   // [buf 2][half 4: A0 A1 W0 W1][128 rows][64]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, r16 = lane & 15;
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int tiles_n = ceil_div(g.N, 256), tiles_m = ceil_div(g.M, 256);
-    const int nblk = tiles_n * tiles_m;
-    int bid = blockIdx.x;
-    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * tiles_n, grp = bid / per_group, first_m = grp * GROUP_M;
-    const int gmn = min(tiles_m - first_m, GROUP_M), inner = bid % per_group;
-    const int bm = first_m + inner % gmn, bn = inner / gmn;
-    const int m0 = bm * 256, n0 = bn * 256;
-    const int nk = g.K / TBK;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // DMA sources: half h, piece i: chunk c = i*512 + tid of the half image (local row c/8, slot c%8; source chunk
-    // = slot ^ (row & 7)).  Local row r of A-half h is tile row (r/64)*128 + h*64 + r%64 (wave-row r/64), of W-half h
-    // tile column (r/32)*64 + h*32 + r%32 (wave-column r/32).
-    const bf16* src[4][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = i * 512 + tid, lrow = c >> 3, ch = (c & 7) ^ (lrow & 7);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int arow = (lrow >> 6) * 128 + h * 64 + (lrow & 63);
-            src[h][i] = g.A + min(m0 + arow, g.M - 1) * g.lda + ch * 8;
-            const int wrow = (lrow >> 5) * 64 + h * 32 + (lrow & 31);
-            src[2 + h][i] = g.W + min(n0 + wrow, g.N - 1) * g.ldw + ch * 8;
-        }
-    }
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    auto dma = [&](int h, int kt, int buf) {
-        const int k0 = min(kt, nk - 1) * TBK;                      // past the end: refill a dead slot (keeps the counts fixed)
-        bf16* dst = lds + (buf * 4 + h) * HALF;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src[h][i] + k0), (lptr_t)(dst + (i * 512 + wave * 64) * 8), 16, 0, 0);
-    };
-    bf16x8 af[2][4], wf[2][2];                                      // [ks][fragment] of the current m-half / n-half
-    auto read_a = [&](int mh, int buf) {
-        const bf16* sa = lds + (buf * 4 + mh) * HALF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + r16;
-                af[ks][i] = *reinterpret_cast<const bf16x8*>(&sa[row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
-            }
-    };
-    auto read_w = [&](int nh, int buf) {
-        const bf16* sb = lds + (buf * 4 + 2 + nh) * HALF;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 32 + j * 16 + r16;
-                wf[ks][j] = *reinterpret_cast<const bf16x8*>(&sb[row * TBK + (((ks * 4 + q) ^ (row & 7)) << 3)]);
-            }
-    };
-    auto mma = [&](int mh, int nh) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[mh * 4 + i][nh * 2 + j] = mfma16(wf[ks][j], af[ks][i], acc[mh * 4 + i][nh * 2 + j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // prologue: A0(0) W1(0) W0(0) A1(0) A0(1) W1(1); the first three must have landed before phase 0 of tile 0
-    dma(0, 0, 0); dma(3, 0, 0); dma(2, 0, 0); dma(1, 0, 0); dma(0, 1, 1); dma(3, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int b = kt & 1;
-        // ---- p0: quadrant (0,0)
-        read_a(0, b);
-        read_w(0, b);
-        dma(2, kt + 1, b ^ 1);                                     // W0(kt+1): its slot was last read in p3 of tile kt-1
-        mma(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- p1: quadrant (0,1)
-        read_w(1, b);
-        dma(1, kt + 1, b ^ 1);                                     // A1(kt+1): slot last read in p2 of tile kt-1
-        mma(0, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // A1(kt) landed (younger: A0,W1,W0,A1 of the next tiles)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- p2: quadrant (1,1)
-        read_a(1, b);
-        dma(0, kt + 2, b);                                         // A0(kt+2) into this tile's A0 slot (last read in p0)
-        mma(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- p3: quadrant (1,0)
-        read_w(0, b);
-        dma(3, kt + 2, b);                                         // W1(kt+2) into this tile's W1 slot (last read in p1)
-        mma(1, 0);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // A0, W1, W0 of tile kt+1 landed
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
-
-    // epilogue (same rounding points as gemm_tile_kernel): acc[i][j][e] <-> m = m0 + wm*128 + i*16 + r16,
-    // n = n0 + wn*64 + j*16 + q*4 + e
-    const bf16x4 z4 = {0, 0, 0, 0};
-    bf16x4 bv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
-        bv[j] = g.bias ? *reinterpret_cast<const bf16x4*>(g.bias + n) : z4;
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + r16;
-        const int mc = min(m, g.M - 1);
-        bf16x4 rv[4], pv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = min(n0 + wn * 64 + j * 16 + q * 4, g.N - 4);
-            rv[j] = g.residual ? *reinterpret_cast<const bf16x4*>(g.residual + (long)mc * g.ldr + n) : z4;
-            pv[j] = g.rowadd ? *reinterpret_cast<const bf16x4*>(g.rowadd + (long)(mc % g.rowadd_period) * g.ldra + n) : z4;
-        }
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + q * 4;
-            if (n >= g.N) continue;
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = rbf(acc[i][j][e] + bf2f(bv[j][e]));
-                if (g.act == ACT_GELU_TANH) x = rbf(gelu_tanh_f(x));
-                else if (g.act == ACT_GELU_ERF) x = rbf(gelu_erf_f(x));
-                else if (g.act == ACT_QUICK_GELU) x = rbf(quick_gelu_bf16(x));
-                if (g.residual) x = rbf(bf2f(rv[j][e]) + x);
-                if (g.rowadd) x = rbf(x + bf2f(pv[j][e]));
-                o[e] = f2bf(x);
-            }
-            *reinterpret_cast<bf16x4*>(g.C + (long)m * g.ldc + n) = o;
-        }
-    }
-}
-
-static hipError_t launch_256(const GemmTileArgs* g, hipStream_t st) {
-    constexpr int lds_bytes = 2 * 4 * 128 * TBK * 2;               // 128 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int nblk = ceil_div(g->N, 256) * ceil_div(g->M, 256);
-    hipLaunchKernelGGL(gemm_tile_256_kernel, dim3(nblk), dim3(512), lds_bytes, st, *g);
-    return hipGetLastError();
-}
-
 // tuning "tile_dma": 0 disables the LDS-DMA family, 1 auto, >= 2 forces variant id (tests, sweeps) whenever K allows
 static int g_tile_dma = 1;
 extern "C" void aha_gemm_tile_set_dma(int on) { g_tile_dma = on; }
@@ -1027,13 +834,8 @@ static hipError_t launch_dma(const GemmTileArgs* g, hipStream_t st) {
 static hipError_t launch_dma_variant(int v, const GemmTileArgs* g, hipStream_t st) {
     switch (v) {
         case 2: return launch_dma<4, 4, 4, 2, 3, true>(g, st);   // 256x128, 8 waves, 144 KB (1 per CU), DMA/MFMA interleave
-        case 3: return launch_dma<2, 4, 4, 2, 4>(g, st);     // 128x128, 8 waves, 128 KB (1 per CU)
-        case 4: return launch_dma<2, 2, 2, 2, 4>(g, st);     //  64x64,  4 waves,  64 KB (2 per CU)
         case 5: return launch_dma<2, 2, 2, 2, 3>(g, st);     //  64x64,  4 waves,  48 KB (3 per CU)
-        case 6: return launch_dma<4, 4, 4, 2, 3, false>(g, st);  // 256x128 with the DMA pieces bunched after the barrier (3-8 % slower)
-        case 7: return launch_256(g, st);                        // 256x256, 8 waves, 128 KB, half-tile refills
         case 8: return launch_dma32<4, 4, 4, 2, 3>(g, st);       // 256x128, 32-deep stages, 72 KB (2 per CU)
-        case 9: return launch_dma32<4, 4, 4, 2, 4>(g, st);       // 256x128, 32-deep stages, 4 x 24 KB = 96 KB (1 per CU)
         case 11: return launch_dma32<9, 2, 2, 4, 3>(g, st);      // 288x128, 32-deep stages, 78 KB (2 per CU): 576-patch towers tile M exactly
         case 21: return launch_dma<3, 2, 2, 2, 3>(g, st);     //  96x64,  4 waves, 3 x 20 KB (2 per CU): fc1 of the latency path (M = 576: 384 tiles instead of 576)
         case 14: return launch_ps64(g, st);                      //  64x64, software-pipelined k-steps, 64 KB (2 per CU): the latency path
@@ -1078,10 +880,6 @@ extern "C" hipError_t aha_gemm_tile(const GemmTileArgs* g_, hipStream_t st) {
         const int nblk_l = ceil_div(g->N, 128) * ceil_div(g->M, 256);
         const float util = (float)nblk_l / (256.f * ceil_div(nblk_l, 256));
         int v = g_tile_dma;
-        if (v == 10) {                                   // experiment: auto, but 256x256 (fewest operand bytes) on wide large grids
-            const int nblk_q = ceil_div(g->N, 256) * ceil_div(g->M, 256);
-            v = (g->N >= 2048 && nblk_q >= 512) ? 7 : 1;
-        }
         if ((g->akb || g->ckb) && !(v == 1 && tile_picks_p288(g))) return hipErrorInvalidValue;   // k-blocked operands: the persistent kernel only (caller asks aha_gemm_tile_will_use_p288 first)
         if (v == 1 && tile_picks_p288(g)) {
             // throughput shapes whose 288 x 256 decomposition keeps the chip busy (tile padding x round quantisation >= 0.70:

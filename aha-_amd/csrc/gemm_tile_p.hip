@@ -21,6 +21,8 @@
 //   * XCD-aware order: the 32 workgroups an XCD runs in a round (blockIdx equal mod 8) take 8 m-panels x 4 n-panels.
 // One output element accumulates its k-steps in the same sequential order as every other variant: bit-identical results
 // (tests/test_gpu_parity.py::test_tiled_gemm_variants_are_bit_identical).
+#include <mutex>
+#include <unordered_map>
 #include "aha_kernels.h"
 #include "tile_act.h"
 #include <unordered_map>
@@ -110,183 +112,6 @@ static __device__ __forceinline__ void p288_epilogue(const GemmTileArgs& g, f32x
 #endif
         }
     }
-}
-
-__global__ __launch_bounds__(512) void gemm_tile_p288_kernel(GemmTileArgs g, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char dsm_raw[];
-    bf16* lds = reinterpret_cast<bf16*>(dsm_raw);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane >> 4, r16 = lane & 15;
-    const int wm = wave >> 2, wn = wave & 3;
-    bf16* stg = lds + PSTAGES * PSTAGE + wave * PSTG;
-    bf16* bias_lds = lds + PSTAGES * PSTAGE + 8 * PSTG + wave * PBIAS;
-
-    const int T = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
-    const int nk = g.K / PBK;
-    const int my_tiles = bid < T ? (T - bid + G - 1) / G : 0;
-    if (my_tiles == 0) return;
-    const int total = my_tiles * nk;
-    const int full_rounds = T / G;
-    // j-th tile of this workgroup -> position in the locality-ordered sequence.  In a full round the workgroups of one XCD
-    // (blockIdx equal mod 8 under round-robin placement: speed only) take G/8 consecutive positions; the ragged last round
-    // keeps the natural order so that the map stays a bijection onto [0, T).
-    auto seq_of = [&](int j) {
-        if ((G & 7) == 0 && j < full_rounds) return (j * 8 + (bid & 7)) * (G >> 3) + (bid >> 3);
-        return j * G + bid;
-    };
-
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-
-    // ---- DMA side: per-piece source offsets (elements from g.A / g.W, without k) of the tile the prefetch stream is in
-    // pieces 0,1: W rows 16 (wave + 8 i) ...; pieces 2,3: A rows 16 (wave + 8 i) ...; piece 4: A rows 256 + 4 wave .. + 3, 4 B per lane
-    const int prow = lane >> 2, pslot = lane & 3;                    // 16-B pieces: 16 rows x 4 slots
-    const int qrow = lane >> 4, qslot = (lane >> 2) & 3, qbyte = (lane & 3) * 4;   // 4-B quarter piece: 4 rows x 4 slots x 4 dwords
-    unsigned poff[PPIECES];
-    int d_j = 0, d_k = 0;                                            // prefetch stream position: tile index, k-step
-    auto set_tile_offsets = [&](int j) {
-        int bm, bn;
-        p288_tile_coords(seq_of(min(j, my_tiles - 1)), tiles_m, tiles_n, &bm, &bn);
-        const int m0 = bm * PBM, n0 = bn * PBN;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int wrow = (wave + 8 * i) * 16 + prow;             // swizzle key: (row >> 2) & 3 with the row index inside its operand
-            poff[i] = (unsigned)min(n0 + wrow, g.N - 1) * (unsigned)g.ldw + ((pslot ^ ((wrow >> 2) & 3)) << 3);
-            const int arow = (wave + 8 * i) * 16 + prow;
-            poff[2 + i] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((pslot ^ ((arow >> 2) & 3)) << 3);
-        }
-        const int arow = 256 + 4 * wave + qrow;
-        poff[4] = (unsigned)min(m0 + arow, g.M - 1) * (unsigned)g.lda + ((qslot ^ ((arow >> 2) & 3)) << 3);
-    };
-    const char* Ab = reinterpret_cast<const char*>(g.A);
-    const char* Wb = reinterpret_cast<const char*>(g.W);
-    // issue piece i of the prefetch stream's current k-step into stage `st`
-    auto dma_piece = [&](int i, int st, int k0) {
-        bf16* sb = lds + st * PSTAGE;
-        if (i < 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Wb + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + (PBM + (wave + 8 * i) * 16) * PBK), 16, 0, 0);
-        else if (i < 4)
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[i] + k0) * 2), (lptr_t)(sb + ((wave + 8 * (i - 2)) * 16) * PBK), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ab + ((size_t)poff[4] + k0) * 2 + qbyte), (lptr_t)(sb + (256 + 4 * wave) * PBK), 4, 0, 0);
-    };
-    // advance the prefetch stream by one k-step (past the last real step it keeps re-reading the last one into dead stages:
-    // the per-wave vmcnt arithmetic stays the same to the end)
-    auto dma_advance = [&]() {
-        if (++d_k == nk) {
-            d_k = 0;
-            ++d_j;
-            set_tile_offsets(d_j);
-        }
-    };
-
-    f32x4 acc[PWI][PWJ];
-#pragma unroll
-    for (int i = 0; i < PWI; ++i)
-#pragma unroll
-        for (int j = 0; j < PWJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // The 64 bias values of this wave's columns for tile j -> its LDS line, one 4-byte LDS-DMA per lane (the upper half of the
-    // 256 bytes is unused padding).  Issued a whole tile before the epilogue that reads it, so the per-step vmcnt waits have
-    // long retired it; always issued (from any valid address when there is no bias) so that the vmcnt arithmetic is fixed.
-    auto bias_dma = [&](int j) {
-        int bm, bn;
-        p288_tile_coords(seq_of(min(j, my_tiles - 1)), tiles_m, tiles_n, &bm, &bn);
-        const int col = min(bn * PBN + wn * (16 * PWJ) + lane * 2, g.N - 2);
-        const char* src = g.bias ? reinterpret_cast<const char*>(g.bias) + col * 2 : Wb;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)bias_lds, 4, 0, 0);
-    };
-    // ---- prologue: the first tile's bias line, then k-steps 0, 1, 2 of the stream into stages 0, 1, 2
-    bias_dma(0);
-    set_tile_offsets(0);
-#pragma unroll
-    for (int s = 0; s < PSTAGES - 1; ++s) {
-        const int k0 = d_k * PBK;
-#pragma unroll
-        for (int i = 0; i < PPIECES; ++i) dma_piece(i, s, k0);
-        dma_advance();
-    }
-
-    int c_j = 0, c_k = 0;                                            // compute stream position
-    int st_cur = 0, st_new = PSTAGES - 1;
-    // k-steps left that were prefetched BEFORE an epilogue's stores: behind them the wave's queue also holds the epilogue's VMEM
-    // operations (18 stores of an interior tile + the bias line), which are younger than the pieces being waited for and must
-    // not be waited for with them (a store takes ~1 us to retire).  relax_n: how many of those are certain to have been issued.
-    int relax = 0, relax_n = 0;
-    for (int step = 0; step < total; ++step) {
-        // this wave's pieces of the current k-step have landed (the two younger k-steps stay in flight); after the barrier
-        // everyone's have, and everyone is done reading the stage that is refilled below
-        if (relax > 0) {
-            --relax;
-            if (relax_n == 19) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PSTAGES - 2) * PPIECES + 19) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PSTAGES - 2) * PPIECES + 1) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PSTAGES - 2) * PPIECES) : "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-
-        const bf16* sa = lds + st_cur * PSTAGE;
-        const bf16* sb = sa + PBM * PBK;
-        const int k0n = d_k * PBK;
-        bf16x8 af[PWI], wf[PWJ];
-#pragma unroll
-        for (int j = 0; j < PWJ; ++j) {
-            const int wrow = wn * (16 * PWJ) + j * 16 + r16;
-            wf[j] = *reinterpret_cast<const bf16x8*>(&sb[wrow * PBK + ((q ^ ((wrow >> 2) & 3)) << 3)]);
-        }
-#pragma unroll
-        for (int i = 0; i < PWI; ++i) {
-            const int row = wm * (16 * PWI) + i * 16 + r16;
-            af[i] = *reinterpret_cast<const bf16x8*>(&sa[row * PBK + ((q ^ ((row >> 2) & 3)) << 3)]);
-        }
-        // 36 MFMAs with the five DMA instructions of k-step (step + 3) spread between them (an LDS-DMA issued while the
-        // matrix pipe is busy costs ~60 cycles; bunched behind the barrier 100-185 each with nothing to overlap)
-        constexpr int NM = PWI * PWJ, PER = NM / (PPIECES + 1);
-#pragma unroll
-        for (int i = 0; i < PWI; ++i)
-#pragma unroll
-            for (int j = 0; j < PWJ; ++j) {
-                acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-                const int n = i * PWJ + j + 1;
-                if (n % PER == 0 && n / PER <= PPIECES) dma_piece(n / PER - 1, st_new, k0n);
-            }
-        __builtin_amdgcn_sched_group_barrier(0x100, PWI + PWJ, 0);             // DS reads
-#pragma unroll
-        for (int i = 0; i < PPIECES; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // VMEM read (LDS-DMA)
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - PPIECES * PER, 0);
-        dma_advance();
-        st_cur = st_cur == PSTAGES - 1 ? 0 : st_cur + 1;
-        st_new = st_new == PSTAGES - 1 ? 0 : st_new + 1;
-
-        if (++c_k < nk) continue;
-        // ---- the tile is complete: epilogue (the prefetch of the next tile's first k-steps is in flight meanwhile)
-        c_k = 0;
-        int bm, bn;
-        p288_tile_coords(seq_of(c_j), tiles_m, tiles_n, &bm, &bn);
-        ++c_j;
-        const int mw = bm * PBM + wm * (16 * PWI), nw = bn * PBN + wn * (16 * PWJ);
-        // one specialisation per (activation, residual, row-add) combination: the per-element switch on g.act would otherwise be
-        // compiled into 576 branchy copies
-        const int combo = g.act * 4 + (g.residual ? 2 : 0) + (g.rowadd ? 1 : 0);
-        switch (combo) {
-            case ACT_NONE * 4 + 0: p288_epilogue<ACT_NONE, false, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            case ACT_NONE * 4 + 1: p288_epilogue<ACT_NONE, false, true>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            case ACT_NONE * 4 + 2: p288_epilogue<ACT_NONE, true, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            case ACT_GELU_TANH * 4 + 0: p288_epilogue<ACT_GELU_TANH, false, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            case ACT_GELU_ERF * 4 + 0: p288_epilogue<ACT_GELU_ERF, false, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            case ACT_QUICK_GELU * 4 + 0: p288_epilogue<ACT_QUICK_GELU, false, false>(g, acc, stg, bias_lds, mw, nw, lane); break;
-            default: p288_epilogue<-1, true, true>(g, acc, stg, bias_lds, mw, nw, lane); break;      // anything else: generic form
-        }
-        bias_dma(c_j);                                             // next tile's bias line (its reads of this one are done)
-        // an interior tile issued all 18 store instructions (a ragged one may have skipped some whose lanes were all out of range)
-        relax = PSTAGES - 1;
-        relax_n = (bm * PBM + PBM <= g.M && bn * PBN + PBN <= g.N) ? 19 : 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing may still target LDS when the block retires
 }
 
 __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, int tiles_m, int tiles_n) {
@@ -544,14 +369,14 @@ __global__ __launch_bounds__(512) void gemm_tile_p288s_kernel(GemmTileArgs g, in
 }
 
 static int g_p288_cus = 0;
-static int g_p288_pipelined = 1;   // 1: software-pipelined fragment reads (gemm_tile_p288s_kernel); 0: the plain k-step loop
-extern "C" void aha_gemm_tile_p288_set_pipelined(int v) { g_p288_pipelined = v; }
 // k-blocked twins of tile-GEMM weights, keyed by the row-major pointer the callers pass (registered by the weight loader, forgotten
 // when their context goes): the kernel's contract stays "W row-major"; the twin only changes where its DMA finds the same bytes.
 struct WkbTwin { const bf16* kb; int N, K; };
 static std::unordered_map<const void*, WkbTwin> g_wkb_map;
+static std::mutex g_wkb_mu;        // contexts on different threads register / forget / look up twins (the table is per process)
 static int g_wkb_on = 1;           // tuning "tile_wkb"
 extern "C" void aha_gemm_tile_kb_register(const void* w, const void* kb, int N, int K) {
+    std::lock_guard<std::mutex> lk(g_wkb_mu);
     if (kb) g_wkb_map[w] = WkbTwin{reinterpret_cast<const bf16*>(kb), N, K};
     else g_wkb_map.erase(w);
 }
@@ -559,17 +384,16 @@ extern "C" void aha_gemm_tile_set_wkb(int on) { g_wkb_on = on; }
 extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g_, hipStream_t st) {
     GemmTileArgs gg = *g_;
     gg.Wkb = nullptr;
-    if (g_wkb_on && g_p288_pipelined && !g_wkb_map.empty() && gg.K % 32 == 0) {
+    if (g_wkb_on && gg.K % 32 == 0) {
+        std::lock_guard<std::mutex> lk(g_wkb_mu);
         auto it = g_wkb_map.find(gg.W);
         if (it != g_wkb_map.end() && it->second.N == gg.N && it->second.K == gg.K) gg.Wkb = it->second.kb;      // the whole matrix, as registered
     }
     const GemmTileArgs* g = &gg;
-    if ((gg.akb || gg.ckb) && (!g_p288_pipelined || (gg.akb && gg.akb != gg.M) || (gg.ckb && (gg.ckb != gg.M || (gg.N & 31))))) return hipErrorInvalidValue;
+    if ((gg.akb && gg.akb != gg.M) || (gg.ckb && (gg.ckb != gg.M || (gg.N & 31)))) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_p288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)gemm_tile_p288s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tile_p288s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PLDS_BYTES);
         if (e != hipSuccess) return e;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -579,10 +403,7 @@ extern "C" hipError_t aha_gemm_tile_p288(const GemmTileArgs* g_, hipStream_t st)
     }
     const int tiles_m = ceil_div(g->M, PBM), tiles_n = ceil_div(g->N, PBN), T = tiles_m * tiles_n;
     int grid = T < g_p288_cus ? T : (g_p288_cus & ~7);            // several rounds: whole XCD groups (the locality order needs gridDim % 8 == 0)
-    if (g_p288_pipelined)
-        hipLaunchKernelGGL(gemm_tile_p288s_kernel, dim3(grid), dim3(512), PLDS_BYTES, st, *g, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_tile_p288_kernel, dim3(grid), dim3(512), PLDS_BYTES, st, *g, tiles_m, tiles_n);
+    hipLaunchKernelGGL(gemm_tile_p288s_kernel, dim3(grid), dim3(512), PLDS_BYTES, st, *g, tiles_m, tiles_n);
     return hipGetLastError();
 }
 

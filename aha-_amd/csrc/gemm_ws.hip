@@ -31,7 +31,7 @@
 template <int MT, int NT, int KC, int EPI, int WPB>
 __global__ __launch_bounds__(WPB * 64, 2) void gemm_ws_kernel(GemmWsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    gemm_ws_body<MT, NT, KC, EPI, WPB, false>(a, blockIdx.x, blockIdx.y, reinterpret_cast<bf16*>(smem_raw), [] {});
+    gemm_ws_body<MT, NT, KC, EPI, WPB>(a, blockIdx.x, blockIdx.y, reinterpret_cast<bf16*>(smem_raw));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -14,14 +14,10 @@ struct WsCfg {
     static constexpr int XLD = (XCH + THREADS - 1) / THREADS;  // staging loads per thread
 };
 
-// The kernel body as a device function: (bx, by) play the role of the launch's block indices so that a persistent
-// kernel can run several "virtual" workgroups; `xs` is the workgroup's LDS staging area (WsCfg::LDS_BYTES).  With
-// PREFETCH_W the first two weight chunks are issued BEFORE `between()` runs (a grid barrier in the fused kernels: the
-// weights do not depend on the previous phase, so they stream during the wait) and the first X tile is loaded after
-// it; without it the order is the stand-alone kernel's (X first, so that the first LDS store does not wait for the
-// weights).
-template <int MT, int NT, int KC, int EPI, int WPB, bool PREFETCH_W, typename Between, bool OUT_SC1 = false>
-static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const int bx, const int by, bf16* xs, Between between) {
+// The kernel body as a device function: (bx, by) = the launch's block indices; `xs` is the workgroup's LDS staging area
+// (WsCfg::LDS_BYTES).  X is loaded first, so that the first LDS store does not wait for the weights.
+template <int MT, int NT, int KC, int EPI, int WPB>
+static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const int bx, const int by, bf16* xs) {
     using C = WsCfg<MT, NT, KC, WPB>;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,19 +96,10 @@ static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const i
     ++c;
 
     const int n = c1 - c0;
-    if constexpr (PREFETCH_W) {
-        if (n > 0) load_w(wA, c0);
-        if (n > 1) load_w(wB, c0 + 1);
-        between();
-    }
     if (n > 0) {
-        if constexpr (PREFETCH_W) {
-            stage_load(c0);
-        } else {
-            stage_load(c0);
-            load_w(wA, c0);
-            if (n > 1) load_w(wB, c0 + 1);
-        }
+        stage_load(c0);
+        load_w(wA, c0);
+        if (n > 1) load_w(wB, c0 + 1);
         stage_store(0);
         __syncthreads();
         int c = c0, buf = 0;
@@ -195,8 +182,7 @@ static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const i
                 const float u = rbf(acc[m][NT - 1][e]);         // up_proj output (bf16)
                 o[e] = f2bf(sg * u);
             }
-            if constexpr (OUT_SC1) store8_sc1(a.out, ((long)row * a.ldo + col) * 2, __builtin_bit_cast(unsigned long long, o));   // handed off inside the launch
-            else *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
+            *reinterpret_cast<bf16x4*>(a.out + (long)row * a.ldo + col) = o;
         }
     } else {  // EPI_F32_RBF: fp32 logits that passed through a bf16 Linear output
 #pragma unroll

@@ -16,10 +16,6 @@ static __device__ __forceinline__ float block_sum_any(float v, float* red) {
     return t;
 }
 
-// One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
-// row).  All threads of the workgroup must call it together.
-// XN_SC1: store xn write-through (buffer_store ... sc1) for a consumer workgroup of the SAME launch (in-launch hand-offs were
-// measured and dropped in rounds 2-4; the flag stays false in the shipped kernels).
 // The 8 elements of chunk c of `row`: split-K slab sum (or the bf16 Linear output), residual add, the updated residual stored; f8 = the
 // new residual values, return = their sum of squares.  Shared by resid_norm_row and by the layer engine's row phase (lm_engine.hip),
 // which must give the same bits: the squares are accumulated with explicit FMAs (left to the compiler, one kernel fused them and
@@ -71,7 +67,8 @@ static __device__ __forceinline__ bf16x8 resid_scale(const float (&f8)[8], const
     return o;
 }
 
-template <bool XN_SC1 = false>
+// One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
+// row).  All threads of the workgroup must call it together.
 static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, const int row, float* red) {
     const int nch = a.H >> 3;
     float ss = 0.f;
@@ -90,8 +87,7 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
                 const bf16x8 o = resid_scale(f8, wv, rstd);
                 // xkb: xn k-blocked [H/32][xkb rows][32] for the mid-M GEMM (gemm_wl.hip), else row-major
                 const long xo = a.xkb ? ((long)(c >> 2) * a.xkb + row) * 32 + (c & 3) * 8 : (long)row * a.ldx + c * 8;
-                if constexpr (XN_SC1) store16_sc1(a.xn, xo * 2, __builtin_bit_cast(u32x4_t, o));
-                else *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
+                *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
             }
             return;
         }

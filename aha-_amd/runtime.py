@@ -399,6 +399,25 @@ class Runtime:
         self._chk(self.lib.aha_heads_forward(self.ctx, hidden.data_ptr(), hidden.shape[1], n, sc.data_ptr(), raw.data_ptr(), _cur_stream()))
         return sc, raw
 
+    def check_rope_rows(self, cos: torch.Tensor, sin: torch.Tensor, pos0: int, T: int):
+        """cos / sin handed to Cache.update ([1,T,D] or [T,D]; a 2-D FULL table is the reference's backward-compatibility form,
+        test/sink_cache.py:113-115) must be rows pos0 .. pos0+T-1 of the runtime's RoPE table: the ring re-rotates with that table."""
+        tc, ts = self._rope_cpu
+        for name, got, tab in (("cos", cos, tc), ("sin", sin, ts)):
+            g = got.detach().to("cpu", torch.bfloat16)
+            g = g[0] if g.dim() == 3 else g
+            if g.dim() != 2 or g.shape[-1] != tab.shape[-1]:
+                raise ValueError(f"cache_kwargs['{name}']: expected [1, T, head_dim] or [T, head_dim]")
+            if g.shape[0] == T:
+                want = tab[pos0:pos0 + T]
+            elif g.shape[0] >= pos0 + T:                      # the full-table form
+                g, want = g[:pos0 + T], tab[:pos0 + T]
+            else:
+                raise ValueError(f"cache_kwargs['{name}'] has {g.shape[0]} rows for {T} new tokens")
+            if want.shape[0] != g.shape[0] or not torch.equal(g, want):
+                raise ValueError(f"cache_kwargs['{name}'] is not the rotary table at positions get_seq_length() + arange(T): the cache "
+                                 "re-rotates kept keys with the runtime's own table (set by Runtime from rope_theta)")
+
     def cache_update(self, stream: Stream, layer_idx: int, k: torch.Tensor, v: torch.Tensor):
         """Cache.update(key_states, value_states, layer_idx, ...) of the reference's cache classes: k, v bf16 [1,Hkv,T,D] (or
         [Hkv,T,D]); returns the (K, V) the reference's update() returns, [1,Hkv,L,D]."""

@@ -213,12 +213,19 @@ def test_config2_sink_and_sliding_10k_frame_streams_with_oracle_prefixes(bench_r
     assert dev.numel() >= 180
     assert dev.mean().item() <= max(SCORE_TOL, 2.0 * band.mean().item()), (dev.mean().item(), band.mean().item())
     assert dev.median().item() <= max(SCORE_TOL, 2.0 * band.median().item()), (dev.median().item(), band.median().item())
+    assert dev.max().item() <= max(SCORE_TOL, 5.0 * band.max().item()), (dev.max().item(), band.max().item())      # loose tail bound: one wrong score cannot hide in a mean
     # two bf16 evaluations are each one band away from the exact answer: their distance is held to sqrt(2) x 2 bands
     d_s = (_rel(sc_slide[:n_slide]) - sb_s).abs()
     print(f"SlidingWindowCache 10k stream, first {n_slide} frames: |hip - oracle_bf16| mean {d_s.mean().item():.2e} median {d_s.median().item():.2e} "
           f"max {d_s.max().item():.2e} (band from the SinkCache replay)")
     assert d_s.numel() >= 180
     assert d_s.mean().item() <= max(SCORE_TOL, 3.0 * band.mean().item()), (d_s.mean().item(), band.mean().item())
+    # the sliding window's OWN fp32 band where it is free: until the window slides (frame ~56) both policies hold the same keys, so the fp32
+    # oracle scores of the SinkCache replay ARE the sliding-window ones for the first 50 frames; the frames behind them get the tail bound
+    dev_s50, band50 = (_rel(sc_slide[:50]) - s32_k[:50]).abs(), band[:50]
+    assert dev_s50.mean().item() <= max(SCORE_TOL, 2.0 * band50.mean().item()), (dev_s50.mean().item(), band50.mean().item())
+    assert dev_s50.max().item() <= max(SCORE_TOL, 5.0 * band50.max().item()), (dev_s50.max().item(), band50.max().item())
+    assert d_s.max().item() <= max(SCORE_TOL, 7.0 * band.max().item()), (d_s.max().item(), band.max().item())       # bf16 vs bf16: sqrt(2) wider
     # before the window slides (frame < 56) the two policies hold the same keys: identical scores
     assert torch.equal(sc_sink[:50], sc_slide[:50])
     for policy, sc in (("default_sink", sc_sink), ("sliding_window", sc_slide)):

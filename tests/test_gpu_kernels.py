@@ -479,6 +479,42 @@ def test_device_ring_reproduces_the_reference_cache_classes_bit_for_bit():
     rt.close()
 
 
+@pytest.mark.parametrize("name,alt", [("sink", "default_sink"), ("sliding", "sliding_window")])
+def test_device_ring_reproduces_the_reference_caches_at_the_benchmark_geometry(name, alt):
+    """tests/golden/cache_bench.npz: the reference's own SinkCache / SlidingWindowCache at W 2048, sink 32,
+    head_dim 128, theta 1e6, 4 KV heads; chunks 20, 71, then 36 x 120, so every kept key goes through its whole life of ~55 bf16
+    re-rotations by sink_rerotate_kernel<128>.  The K and V that aha_cache_update returns carry the reference's bits at EVERY step
+    and layer (sha256), and the sampled rows (sink edge, first kept key, ring middle, new-chunk edge, last key) match one by one."""
+    import dataclasses
+    from aha_amd.config import preset
+    from aha_amd.runtime import Runtime
+    import make_golden as mg
+    base = preset("tiny")
+    cfg = dataclasses.replace(base, lm=dataclasses.replace(base.lm, num_hidden_layers=mg.BENCH_LAYERS, num_attention_heads=mg.BENCH_HKV,
+                                                           num_key_value_heads=mg.BENCH_HKV, head_dim=mg.BENCH_D, rope_theta=mg.BENCH_THETA),
+                              name="cachebench")
+    rt = Runtime(cfg, make_weights(cfg, dtype=torch.bfloat16), max_step_tokens=128, max_vit_frames=1, max_positions=4096)
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "cache_bench.npz"))
+    st = rt.open_stream(alt, mg.BENCH_W, mg.BENCH_SINK if name == "sink" else 0)
+    first_bad = None
+    for step, (T, layers) in enumerate(mg.bench_cache_inputs()):
+        assert st.get_seq_length() == int(gold[f"{name}_len_before"][step]), (name, step)
+        for l, (k, v) in enumerate(layers):
+            Kr, Vr = rt.cache_update(st, l, k.cuda(), v.cuda())
+            Kc, Vc = Kr.cpu(), Vr.cpu()
+            if step in mg.BENCH_SAMPLE_STEPS:
+                rows = [r for r in mg.BENCH_SAMPLE_ROWS if r < Kc.shape[2]]
+                assert np.array_equal(mg.bf16_bits(Kc[0, 1, rows]), gold[f"{name}_k_s{step}_l{l}"]), (name, step, l, "K rows")
+                assert np.array_equal(mg.bf16_bits(Vc[0, 1, rows]), gold[f"{name}_v_s{step}_l{l}"]), (name, step, l, "V rows")
+            ok = np.array_equal(mg.kv_digest(Kc), gold[f"{name}_digest"][step, l, 0]) and np.array_equal(mg.kv_digest(Vc), gold[f"{name}_digest"][step, l, 1])
+            if not ok and first_bad is None:
+                first_bad = (step, l)
+    assert first_bad is None, f"{name}: returned K/V differ from the reference's from step {first_bad[0]}, layer {first_bad[1]}"
+    assert st.get_seq_length() == int(gold[f"{name}_len_final"]) == mg.BENCH_W
+    st.close()
+    rt.close()
+
+
 @pytest.mark.gpu
 def test_python_cache_classes_update_reproduces_the_reference_fixture():
     """The drop-in's SinkCache / SlidingWindowCache / TrulyStaticCache objects take the reference's operator call
@@ -488,7 +524,7 @@ def test_python_cache_classes_update_reproduces_the_reference_fixture():
     from aha_amd.cache import SinkCache, SlidingWindowCache, TrulyStaticCache
     from aha_amd.config import preset
     from aha_amd.runtime import Runtime
-    from make_golden import CACHE_D, CACHE_HKV, CACHE_LAYERS, CACHE_SINK, CACHE_STEPS, CACHE_THETA, CACHE_W, bf16_bits, cache_inputs
+    from make_golden import CACHE_D, CACHE_HKV, CACHE_LAYERS, CACHE_SINK, CACHE_STEPS, CACHE_THETA, CACHE_W, bf16_bits, cache_inputs, rope_table
     base = preset("tiny")
     cfg = dataclasses.replace(base, lm=dataclasses.replace(base.lm, num_hidden_layers=CACHE_LAYERS, num_key_value_heads=CACHE_HKV,
                                                            head_dim=CACHE_D, rope_theta=CACHE_THETA), name="cachegold")
@@ -502,8 +538,19 @@ def test_python_cache_classes_update_reproduces_the_reference_fixture():
         assert cache.get_max_length() == CACHE_W and cache.get_max_cache_shape() == CACHE_W
         for step, (T, layers) in enumerate(cache_inputs()):
             assert cache.get_seq_length() == int(gold[f"{name}_len_before"][step]), (name, step)
+            L = cache.get_seq_length()
+            cos, sin = rope_table((L + torch.arange(T))[None], CACHE_D, CACHE_THETA, torch.bfloat16)
             for l, (k, v) in enumerate(layers):
-                kw = {"sin": None, "cos": None, "cache_position": None}                # 4.49-style kwargs: accepted, unused
+                kw = {"sin": sin.cuda(), "cos": cos.cuda(), "cache_position": None}    # 4.49-style kwargs, as Qwen2Attention passes them
+                if name == "sink" and step == 0 and l == 0:
+                    with pytest.raises(ValueError):                                    # the reference would shift WITHOUT re-rotating: refused, loudly
+                        cache.update(k.cuda(), v.cuda(), l, {"sin": None, "cos": None})
+                    with pytest.raises(NotImplementedError):
+                        cache.update(k.cuda(), v.cuda(), l, {"sin": sin.cuda(), "cos": cos.cuda(), "partial_rotation_size": 32})
+                    with pytest.raises(ValueError):                                    # positions that are not get_seq_length() + arange(T)
+                        bad = rope_table((L + 5 + torch.arange(T))[None], CACHE_D, CACHE_THETA, torch.bfloat16)
+                        cache.update(k.cuda(), v.cuda(), l, {"cos": bad[0].cuda(), "sin": bad[1].cuda()})
+                    assert cache.get_seq_length() == L                                 # a refused call changes nothing
                 Kr, Vr = cache.update(k.cuda()[None] if k.dim() == 3 else k.cuda(), v.cuda()[None] if v.dim() == 3 else v.cuda(), l, kw)
                 assert Kr.dim() == 4 and Kr.shape[0] == 1
                 if f"{name}_k_s{step}_l{l}" in gold:

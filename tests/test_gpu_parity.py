@@ -360,6 +360,10 @@ def test_full_size_28_layers_match_oracle_within_its_own_bf16_band(bench_rt):
         print(f"full-size band diagnostic [{policy}]: |hip - fp32| median {d_.median().item():.2e} max {d_.max().item():.2e}; "
               f"|oracle_bf16 - fp32| median {b_.median().item():.2e} max {b_.max().item():.2e}")
         assert torch.isfinite(d_).all()
+        # per policy: the mean rule, and a loose tail bound - one grossly wrong score (a wrong eviction row on one step)
+        # cannot hide inside a pooled mean
+        assert d_.mean().item() <= max(SCORE_TOL, 3.0 * b_.mean().item()), (policy, d_.mean().item(), b_.mean().item())
+        assert d_.max().item() <= max(SCORE_TOL, 5.0 * b_.max().item()), (policy, d_.max().item(), b_.max().item())
         st.close()
     dev, band = torch.cat(dev), torch.cat(band)
     assert dev.numel() >= 48 and dev.mean().item() <= max(SCORE_TOL, 3.0 * band.mean().item()), (dev.mean().item(), band.mean().item())
@@ -565,20 +569,20 @@ def test_long_sink_stream_bookkeeping_and_reproducibility(bench_rt):
 
 
 def test_lds_dma_gemm_matches_register_staged_gemm(bench_rt):
-    """Every LDS-DMA tile GEMM variant (256x128 with / without the DMA-MFMA interleave, 128x128, 64x64 at 4 and 3
-    stages, 96x64, 256x256 with half-tile refills, the 32-deep 256x128 and 288x128 tiles, the persistent 288x256 tile; counted vmcnt) accumulates an
+    """Every LDS-DMA tile GEMM variant the product can select (256x128 with the DMA-MFMA interleave, 64x64 at 3 stages and
+    software-pipelined, 96x64, the 32-deep 256x128 and 288x128 tiles, the persistent 288x256 tile; counted vmcnt) accumulates an
     output element's k-tiles in the same order as the register-staged kernel, so forcing each of them on 3 frames
     (M = 1731, ragged last m-tile) and on 1 frame must reproduce it bit for bit."""
     cfg, rt = bench_rt
     for n in (3, 1):
         fr = make_frames(n, cfg.vision.image_size, seed=21).cuda()
         outs = {}
-        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 21):
+        for mode in (0, 1, 2, 5, 8, 11, 12, 14, 21):
             rt.set_tuning("tile_dma", mode)
             outs[mode] = rt.visual_embed(fr).clone()
         rt.set_tuning("tile_dma", 1)
         assert torch.isfinite(outs[0].float()).all()
-        for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 14, 21):
+        for mode in (1, 2, 5, 8, 11, 12, 14, 21):
             assert torch.equal(outs[0], outs[mode]), f"tile_dma={mode} differs from the register-staged GEMM on {n} frame(s)"
 
 
@@ -753,25 +757,28 @@ def test_row_blocks_above_256_stay_bit_identical():
     g = torch.Generator().manual_seed(41)
     pre = (torch.randn(B, 20, H, generator=g) * 0.3).bfloat16().cuda()
     x = (torch.randn(B, tf, H, generator=g) * 0.3).bfloat16().cuda()
-    solo, solo_act = [], []
+    solo, solo_act, solo_attn = [], [], []
     for b in range(B):
         st = rt.open_stream("default_sink", 128, 8)
         rt.lm_step([st], pre[b:b + 1])
         solo.append(rt.lm_step([st], x[b:b + 1]).clone())
         solo_act.append(rt.debug_tap("act", 1, tf).clone())   # SwiGLU activation of the last layer, [36][inter]
+        solo_attn.append(rt.debug_tap("attn_out", 1, tf).clone())   # attention output of the last layer, [36][heads*head_dim]
         st.close()
-    # act_kb = 2 (default): the mid-M kernels pass the normed gate/up input and the SwiGLU activation k-blocked; 1: the
-    # activation only; 0: row-major.  Same bits, and the parity tap un-blocks the activation.
-    for act_kb in (2, 1, 0):
+    # act_kb = 3 (default): the mid-M kernels pass the normed gate/up input, the SwiGLU activation AND the QKV / o_proj inputs
+    # k-blocked (the cache-attention and combine kernels then store the attention output k-blocked, the taps un-block); 2: the MLP
+    # operands only; 1: the activation only; 0: row-major.  Same bits at every level.
+    for act_kb in (3, 2, 1, 0):
         rt.set_tuning("act_kb", act_kb)
         sts = [rt.open_stream("default_sink", 128, 8) for _ in range(B)]
         rt.lm_step(sts, pre)
         batched = rt.lm_step(sts, x)                   # 288 rows in one step
         assert torch.isfinite(batched).all() and torch.equal(batched, torch.cat(solo)), act_kb
         assert torch.equal(rt.debug_tap("act", B, tf), torch.cat(solo_act)), act_kb
+        assert torch.equal(rt.debug_tap("attn_out", B, tf), torch.cat(solo_attn)), act_kb
         for st in sts:
             st.close()
-    rt.set_tuning("act_kb", 2)
+    rt.set_tuning("act_kb", 3)
     rt.close()
 
 

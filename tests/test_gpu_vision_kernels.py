@@ -17,6 +17,7 @@ import math
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -99,18 +100,21 @@ def _qkv_with_probes(n, T, H, D, targets, g):
     return q, k, v
 
 
-@pytest.mark.parametrize("case", ["vitl_576x64", "ragged_500x64", "so400m_729x72"])
+@pytest.mark.parametrize("case", ["vitl_576x64", "vitl_576x64_3frames", "vitl_576x64_1frame", "ragged_500x64", "so400m_729x72"])
 def test_dense_attention_flat_bound(vit_l, case):
+    """8 frames: the 12-wave head-resident kernel; 1 and 3 frames: its 4-wave row-group form (the latency path's choice) -
+    each against the restaging kernel (attn_head = 0) bit for bit and against the exact result within the flat bound."""
     cfg, _, rt = vit_l
-    T, H, D, n = {"vitl_576x64": (576, 16, 64, 8), "ragged_500x64": (500, 16, 64, 8), "so400m_729x72": (729, 16, 72, 2)}[case]
-    g = _gen({"vitl_576x64": 1, "ragged_500x64": 2, "so400m_729x72": 3}[case])
+    T, H, D, n = {"vitl_576x64": (576, 16, 64, 8), "vitl_576x64_3frames": (576, 16, 64, 3), "vitl_576x64_1frame": (576, 16, 64, 1),
+                  "ragged_500x64": (500, 16, 64, 8), "so400m_729x72": (729, 16, 72, 2)}[case]
+    g = _gen({"vitl_576x64": 1, "vitl_576x64_3frames": 6, "vitl_576x64_1frame": 7, "ragged_500x64": 2, "so400m_729x72": 3}[case])
     targets = sorted({j for j in (0, 1, 15, 16, 63, 64, 65, 127, 128, 255, 256, 319, 320, 447, 448, 511, 512, T - 65, T - 64, T - 2, T - 1) if 0 <= j < T})
     q, k, v = _qkv_with_probes(n, T, H, D, targets, g)
     qkv = torch.cat([q.reshape(n, T, H * D), k.reshape(n, T, H * D), v.reshape(n, T, H * D)], dim=-1)
     exact, pav = _dense_exact(q, k, v, D ** -0.5)
     outs = {}
     try:
-        for mode in ((0, 2) if D == 64 else (1,)):
+        for mode in ((0, 1, 2) if D == 64 else (1,)):          # 1 (auto): the 4-wave row-group form below 8 frames, the 12-wave form from 8 up; 2: always the 12-wave form
             rt.set_tuning("attn_head", mode)
             got = rt.vit_attention(qkv, H, D).view(n, T, H, D)
             e = ulp_error(got, exact, floor=2.0 ** -10, slack=(2.0 ** -8 + 1e-4) * pav)
@@ -124,7 +128,7 @@ def test_dense_attention_flat_bound(vit_l, case):
     finally:
         rt.set_tuning("attn_head", 1)
     if D == 64:
-        assert torch.equal(outs[0], outs[2]), "head-resident and restaging dense attention kernels must agree bit for bit"
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[1]), "head-resident (both forms) and restaging dense attention kernels must agree bit for bit"
     else:
         # 72 channels run the 96-wide template; tuning attn_d96 = 0 pads them to the 128-wide one (round 2): same bits
         try:
@@ -133,6 +137,26 @@ def test_dense_attention_flat_bound(vit_l, case):
         finally:
             rt.set_tuning("attn_d96", 1)
         assert torch.equal(outs[1], wide), "the 96- and 128-wide dense attention templates must agree bit for bit"
+
+
+def test_vision_path_operand_layouts_and_riders_do_not_change_a_bit(vit_l):
+    """the round-5 defaults of the tower - k-blocked activations (vit_akb), k-blocked weight twins (tile_wkb), the LayerNorm
+    launches' weight-prefetch riders (vit_prefetch) and the head-resident attention in both forms (attn_head) - against the row-major /
+    restaging paths they replaced: whole encodes of 1, 3 and 8 frames, bit for bit."""
+    cfg, _, rt = vit_l
+    fr = make_frames(8, cfg.vision.image_size, seed=9).cuda()
+    base = {n: rt.visual_embed(fr[:n]).clone() for n in (1, 3, 8)}
+    for n in base:
+        assert torch.isfinite(base[n].float()).all()
+    for key, off, on in (("vit_akb", 0, 1), ("tile_wkb", 0, 1), ("vit_prefetch", 0, 2400), ("attn_head", 0, 1), ("tile_p288", 0, 1)):
+        try:
+            rt.set_tuning(key, off)
+            for n in (1, 3, 8):
+                assert torch.equal(rt.visual_embed(fr[:n]), base[n]), (key, n)
+        finally:
+            rt.set_tuning(key, on)
+    for n in (1, 3, 8):
+        assert torch.equal(rt.visual_embed(fr[:n]), base[n]), n
 
 
 def test_dense_attention_kernel_choice_does_not_depend_on_the_batch(vit_l):
@@ -174,6 +198,39 @@ def test_preprocess_and_patch_unfold_is_exact(vit_l):
     assert got.shape == (3 * 576, 640)
     assert torch.equal(got[:, :588], want)
     assert (got[:, 588:] == 0).all()
+
+
+@pytest.mark.parametrize("grid,stride,mode", [(27, 4, "bilinear"), (24, 4, "bilinear"), (27, 4, "average"), (24, 4, "average"), (27, 4, "max"), (24, 4, "max")])
+def test_pooling_against_the_reference_function_itself(vit_l, grid, stride, mode):
+    """tests/golden/ref_pooling.npz = outputs of the reference's own post_projector_pooling (video_head_live_llava_qwen.py:117-136,
+    compiled unmodified from its source text by tests/make_golden.py) on seeded features, in bf16 and fp32.  The HIP pool kernel on the
+    same bf16 features: within one bf16 ulp of the reference's fp32 result (the reference's bf16 result itself is), max pooling exact."""
+    import make_golden as mg
+    _, _, rt = vit_l
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ref_pooling.npz"))
+    want32 = torch.from_numpy(gold[f"{mode}_{grid}_f32"])
+    want16 = torch.from_numpy(gold[f"{mode}_{grid}_bf16"].view(np.int16)).view(torch.bfloat16)
+    out_grid = int(round(want32.shape[1] ** 0.5))
+    x = mg.pool_input(grid).bfloat16().cuda()
+    got = rt.pool(x, grid, out_grid, stride, {"bilinear": 0, "average": 1, "max": 2}[mode]).cpu()
+    assert got.shape == want16.shape
+    # the fp32 fixture was computed from fp32 features; judge both bf16 results against an fp64 evaluation of the bf16 features
+    xs = mg.pool_input(grid).bfloat16().double().view(2, grid, grid, -1).permute(0, 3, 1, 2)
+    if mode == "bilinear":
+        ex = F.interpolate(xs, size=[out_grid, out_grid], mode="bilinear")
+    elif mode == "average":
+        ex = F.avg_pool2d(xs, stride)
+    else:
+        ex = F.max_pool2d(xs, stride)
+    ex = ex.permute(0, 2, 3, 1).reshape(2, out_grid * out_grid, -1)
+    e_ref = ulp_error(want16, ex, floor=2.0 ** -10)
+    e_got = ulp_error(got, ex, floor=2.0 ** -10)
+    assert e_ref.max().item() <= 1.0 + 1e-6 and e_got.max().item() <= 1.0 + 1e-6, (e_ref.max().item(), e_got.max().item())
+    d = ulp_error(got, want16.double(), floor=2.0 ** -10)
+    assert d.max().item() <= 1.0 + 1e-6, d.max().item()            # never further than one ulp from what the reference returns
+    assert (got == want16).float().mean().item() >= 0.98
+    if mode == "max":
+        assert torch.equal(got, want16)
 
 
 @pytest.mark.parametrize("grid,out_grid,mode", [(24, 6, 0), (27, 7, 0), (24, 6, 1), (24, 6, 2), (24, 7, 3), (27, 7, 3), (24, 1, 3)])

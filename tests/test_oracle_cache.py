@@ -39,6 +39,28 @@ def test_policy_matches_reference_golden(name):
     assert pol.get_seq_length() == int(gold[f"{name}_len_final"])
 
 
+@pytest.mark.parametrize("name", ["sink", "sliding"])
+def test_policy_matches_the_reference_at_the_benchmark_geometry(name):
+    """tests/golden/cache_bench.npz: the reference's own SinkCache / SlidingWindowCache at W 2048, sink 32, head_dim 128, theta 1e6,
+    4 KV heads over 122 steps (a key lives its whole ~55 bf16 re-rotations): the oracle returns the same K and V bits at EVERY step
+    (sha256 per step and layer), the sampled rows included."""
+    gold = np.load(os.path.join(GOLDEN, "cache_bench.npz"))
+    pol = SinkPolicy(mg.BENCH_W, mg.BENCH_SINK) if name == "sink" else SlidingPolicy(mg.BENCH_W)
+    for step, (T, layers) in enumerate(mg.bench_cache_inputs()):
+        L = pol.get_seq_length()
+        assert L == int(gold[f"{name}_len_before"][step])
+        cos, sin = mg.rope_table((L + torch.arange(T))[None], mg.BENCH_D, mg.BENCH_THETA, torch.bfloat16)
+        for l, (k, v) in enumerate(layers):
+            kr, vr = pol.update(k, v, l, {"cos": cos, "sin": sin})
+            assert np.array_equal(mg.kv_digest(kr), gold[f"{name}_digest"][step, l, 0]), (name, step, l, "K")
+            assert np.array_equal(mg.kv_digest(vr), gold[f"{name}_digest"][step, l, 1]), (name, step, l, "V")
+            if step in mg.BENCH_SAMPLE_STEPS:
+                rows = [r for r in mg.BENCH_SAMPLE_ROWS if r < kr.shape[2]]
+                assert np.array_equal(mg.bf16_bits(kr[0, 1, rows]), gold[f"{name}_k_s{step}_l{l}"])
+                assert np.array_equal(mg.bf16_bits(vr[0, 1, rows]), gold[f"{name}_v_s{step}_l{l}"])
+    assert pol.get_seq_length() == int(gold[f"{name}_len_final"]) == mg.BENCH_W
+
+
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference not present (GPU box)")
 def test_policy_matches_reference_live():
     sys.path.insert(0, "/root/reference")

@@ -1,5 +1,5 @@
-"""Per-shape sweep of the tiled-GEMM variants through the developer hook aha_dev_gemm_tile (variant 12 = persistent 288x256 with
-the plain k-step loop, 13 = the same kernel with software-pipelined fragment reads).
+"""Per-shape sweep of the tiled-GEMM variants through the developer hook aha_dev_gemm_tile (variant 12 = persistent 288x256; 13 is
+accepted as an alias from the time a plain-loop form of that kernel existed).
 Weights cycle over 24 distinct buffers (a tower's worth), so they stream from HBM as in the real encode."""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +7,6 @@ lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", os.environ.get("AHA_SWEEP_LIB",
 lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 _raw = lib.aha_dev_gemm_tile
 def dev_gemm(A, W, C, M, N, K, v, st):
-    lib.aha_gemm_tile_p288_set_pipelined(1 if v == 13 else 0)
     return _raw(A, W, C, M, N, K, 12 if v == 13 else v, st)
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
 Ms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [576, 1152, 2304, 4608, 18432]

@@ -15,7 +15,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 st = torch.cuda.current_stream().cuda_stream
 bad = total = 0
 g = torch.Generator(device="cuda").manual_seed(1)
-# persistent 288x256 (pipelined = variant 12 with the default switch, plain loop with tile_p288s = 0) and the pipelined 64x64 (14)
+# persistent 288x256 (variant 12) and the pipelined 64x64 (14), each against an independently synchronised kernel (register-staged or 32-deep DMA tile)
 for M, N, K in [(18432, 3072, 1024), (18432, 1024, 4096), (9792, 4096, 1024), (18432 + 100, 1152, 640), (4608, 3584, 3584), (73728, 1024, 1024),
                 (576, 1024, 4096), (576, 3072, 1024), (1731, 1024, 1024)]:
     A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).bfloat16()
@@ -23,9 +23,8 @@ for M, N, K in [(18432, 3072, 1024), (18432, 1024, 4096), (9792, 4096, 1024), (1
     ref = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     out = torch.empty_like(ref)
     assert lib.aha_dev_gemm_tile(A.data_ptr(), W.data_ptr(), ref.data_ptr(), M, N, K, 0 if M < 4000 else 8, st) == 0
-    for variant, piped in ((12, 1), (12, 0), (14, 1)):
+    for variant, piped in ((12, 1), (14, 1)):
         if variant == 14 and M > 2304: continue
-        lib.aha_gemm_tile_p288_set_pipelined(piped)
         n_bad = 0
         for r in range(rounds):
             out.fill_(7.0)
@@ -33,7 +32,6 @@ for M, N, K in [(18432, 3072, 1024), (18432, 1024, 4096), (9792, 4096, 1024), (1
             n_bad += int(not torch.equal(out, ref))
         total += rounds; bad += n_bad
         print(f"gemm M={M:6d} N={N:5d} K={K:5d} variant {variant}{'s' if piped and variant == 12 else ''}: {n_bad} of {rounds} launches differ", flush=True)
-lib.aha_gemm_tile_p288_set_pipelined(1)
 # head-resident dense attention against the restaging kernel
 cfg = preset("tiny")
 rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16), max_step_tokens=64, max_vit_frames=1, max_positions=256)
