@@ -116,7 +116,7 @@ def pmc_traffic(kernel_prefix, workload):
     other workload, or a summary that does not say, give None.  `kernel_prefix` may be a tuple: the launches of one timed group
     (cache attention + its combine kernel) - their bytes are added, and every one of them must have a row."""
     prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
-    for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
