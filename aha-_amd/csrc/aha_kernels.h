@@ -121,6 +121,17 @@ struct EngArgs {
     int exp;                         // experiment bits (tuning "engine_exp")
 };
 
+// the register-streaming MLP launch (lm_stream.hip): gate/up + SwiGLU -> down_proj, gemm_ws_kernel's work split
+struct MlpStreamArgs {
+    GemmWsArgs gu, dn;               // gate/up (S = 1, out = act row-major, written through) and down_proj (S slices, partial slabs; X = gu.out)
+    int M;
+    int gu_blocks, gu_wpb;           // gate/up: workgroups and waves per workgroup that own a pair (237 x 5 at Qwen2-7B)
+    int dn_bx, dn_wpb;               // down_proj: workgroups per K slice and tiles (= waves with a tile) per workgroup; the last wave of a workgroup never owns tiles: it polls
+    unsigned* sync;                  // [32 * (1 + s)]: gate/up pairs done of down_proj slice s; zeroed before the step
+    int* err;                        // sticky device error word
+    unsigned long long* stamps;      // diagnostic: [grid][16] wall-clock stamps (null in the product)
+};
+
 // frame ingest (ingest.hip): one source frame -> one [3,S,S] canvas
 struct IngestArgs {
     const uint8_t* src; int h, w, src_bgr;       // uint8 [h][w][3]; src_bgr: channels arrive B,G,R
@@ -166,6 +177,8 @@ void aha_attention_set_d96(int v);
 extern "C" void aha_gemm_wl_set_balanced(int on);
 hipError_t aha_attention(const AttnArgs* a, const StepDesc* sd_dev, int B, int head_dim, hipStream_t st);   // sd_dev: DEVICE pointer or null (dense)
 hipError_t aha_lm_engine(const EngArgs* a, hipStream_t st);
+hipError_t aha_lm_mlp_stream(const MlpStreamArgs* p, int grid, hipStream_t st);
+int aha_lm_mlp_stream_ok(int gu_KS, int dn_KS, int dn_S);
 int aha_lm_engine_lds_bytes();
 int aha_lm_engine_rows();
 int aha_lm_engine_ntmax();

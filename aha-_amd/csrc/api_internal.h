@@ -119,9 +119,10 @@ struct aha_ctx {
     int static_attn = 1;                 // frozen-static steps with a prefix <= 64 keys: qkv_finish + attention in one launch (tuning "static_attn")
     int fuse_static = 0;                 // frozen-static steps: skip K/V projection + Q built inside attention (tuning key
                                          // "fuse_static"; bit-identical, measured 0 % gain: the chain is latency-bound)
-    // persistent layer engine (lm_engine.hip; tuning "engine": 0 off (default), 1 = single-stream steps (M <= 48 rows) run the MLP half of
-    // every layer - post-attention resid_norm, gate/up + SwiGLU, down_proj - as one persistent launch).  Bit-identical; measured 5 % SLOWER
-    // than the three launches on the whole step (profiles/r06_engine_mlp_stamps.txt), so it is an experiment, not the product path.
+    // single-launch forms of a layer's MLP half on single-stream steps (M <= 48 rows); tuning "engine": 0 off (default), 1 = lm_engine.hip
+    // (LDS-DMA loader ring: resid_norm + gate/up + SwiGLU + down_proj; measured 5 % slower on the whole step), 2 = lm_stream.hip (register
+    // streaming: gate/up + SwiGLU -> down_proj; measures what the two launches measure).  Both bit-identical (tests/test_gpu_layers.py);
+    // experiments, not the product path (profiles/r06_engine_mlp_stamps.txt).
     int engine = 0;
     bf16 *eng_xn = nullptr, *eng_act = nullptr;             // hand-off panels [K/32][48][32]
     unsigned* eng_sync = nullptr;                           // [layers][16 counters, one per 128-byte line], zeroed once per step

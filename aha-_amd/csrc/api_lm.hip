@@ -320,11 +320,24 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     const bool qkv_kb = c->act_kb >= 3 && H % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, H);
     const bool o_kb = c->act_kb >= 3 && QD % 32 == 0 && Dh % 32 == 0 && ws_all_wl(c, EPI_PARTIAL, M, QD) && !static_attn && !frozen_all;
     c->attn_kb_rows = o_kb ? M : 0;
-    // single-stream steps: the MLP half of every layer as one persistent launch (lm_engine.hip); same bits as the launches
-    const bool use_eng = c->engine && M <= aha_lm_engine_rows() && !c->time_gemm && pick_split(c, GK_O, c->L[0].o, M, 1) <= 8 && eng_prepare(c) && pick_split(c, GK_DOWN, c->L[0].down, M, 1) == c->eng_G;
+    // single-stream steps: the MLP half of every layer as one launch - engine 2: register-streaming form (lm_stream.hip), engine 1: the LDS-DMA
+    // ring (lm_engine.hip); same bits as the launches either way
+    bool use_st = false;
+    if (c->engine == 2 && M <= 48 && !c->time_gemm && c->n_cus >= M) {
+        const PackedW& gu = c->L[0].gateup; const PackedW& dn = c->L[0].down;
+        const int Sd0 = pick_split(c, GK_DOWN, dn, M, 1);
+        const int gub = ceil_div(gu.n_tiles, 2 * c->wpb[GK_GATEUP]), dnb = ceil_div(dn.n_tiles, 7) * Sd0;
+        use_st = c->wpb[GK_GATEUP] <= 7 && gub <= c->n_cus && dnb <= c->n_cus && Sd0 <= 14 &&
+                 aha_lm_mlp_stream_ok(gu.KS, dn.KS, Sd0) == 1;
+        if (use_st && !c->eng_sync) {
+            if (dalloc(c, &c->eng_sync, (size_t)d.layers * 512)) return AHA_E_NOMEM;
+            HIPCHK(c, hipMemset(c->eng_sync, 0, (size_t)d.layers * 512 * sizeof(unsigned)));
+        }
+    }
+    const bool use_eng = !use_st && c->engine == 1 && M <= aha_lm_engine_rows() && !c->time_gemm && pick_split(c, GK_O, c->L[0].o, M, 1) <= 8 && eng_prepare(c) && pick_split(c, GK_DOWN, c->L[0].down, M, 1) == c->eng_G;
     c->eng_ran = use_eng ? M : 0;
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
-        if (use_eng) HIPCHK(c, hipMemsetAsync(c->eng_sync, 0, (size_t)d.layers * 512 * sizeof(unsigned), st));
+        if (use_eng || use_st) HIPCHK(c, hipMemsetAsync(c->eng_sync, 0, (size_t)d.layers * 512 * sizeof(unsigned), st));
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
 
@@ -389,7 +402,18 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
             ra.partial = c->partial; ra.S = So; ra.slab_stride = (long)M * H; ra.ldp = H;
             ra.h = c->h; ra.ldh = H; ra.w = w.ln2; ra.xn = c->xn; ra.ldx = H; ra.H = H; ra.eps = d.rms_eps;
             const int Sd = pick_split(c, GK_DOWN, w.down, M, 1);
-            if (use_eng) {
+            if (use_st) {
+                MlpStreamArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                HIPCHK(c, aha_resid_norm(&ra, M, st));          // the rows stay a launch of their own: a kernel boundary is the cheaper all-to-all hand-off (lm_stream.hip)
+                sa.gu = ws_args(c->xn, H, M, 0, M, w.gateup, 1, nullptr, 0, c->act, I, nullptr, 0);
+                sa.dn = ws_args(c->act, I, M, 0, M, w.down, Sd, c->partial, H, nullptr, 0, nullptr, 0);
+                sa.M = M; sa.gu_wpb = c->wpb[GK_GATEUP]; sa.gu_blocks = ceil_div(w.gateup.n_tiles, 2 * sa.gu_wpb); sa.dn_wpb = 7; sa.dn_bx = ceil_div(w.down.n_tiles, sa.dn_wpb);
+                sa.sync = c->eng_sync + (size_t)l * 512; sa.err = c->bar_err; sa.stamps = c->eng_stamps;
+                HIPCHK(c, aha_lm_mlp_stream(&sa, c->n_cus, st));
+                c->last_weight_bytes += w.gateup.bytes() + w.down.bytes();
+                c->last_flops += 2.0 * ((double)w.gateup.n_tiles * 16.0 * w.gateup.K + (double)w.down.n_tiles * 16.0 * w.down.K) * (double)M;
+            } else if (use_eng) {
                 EngArgs ea;
                 memset(&ea, 0, sizeof(ea));
                 ea.rn = ra; ea.rn.xn = c->eng_xn; ea.rows_idx = 0;
@@ -443,7 +467,7 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     for (int b = 0; b < B; ++b)
         if (sd.s[b].write_base >= 0 && guard.saved[b][0] + sd.s[b].write_count > sd.s[b].len_after) guard.destructive = true;
     const double attn_flops = 4.0 * T * (double)max_lk * QD * B * d.layers;
-    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0) | (use_eng ? 8 : 0);
+    const int gflags = (q_only ? 1 : 0) | (frozen_all ? 2 : 0) | (static_attn ? 4 : 0) | (use_eng ? 8 : 0) | (use_st ? 16 : 0);
     // (While GEMM launches are being timed the step is launched directly: a plain hipEventRecord issued during stream capture
     // does not become a graph node, so a replay would leave the events holding stale timestamps.)
     if (c->use_graph && out_scores && !out_raw && !out_last_hidden && !c->time_gemm && !c->eng_stamps) {

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16* __restrict__ x
 
 __global__ __launch_bounds__(512) void resid_norm_kernel(ResidNormArgs a) {
     __shared__ float red[16];
-    resid_norm_row(a, blockIdx.x, red);
+    resid_norm_row<false>(a, blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------

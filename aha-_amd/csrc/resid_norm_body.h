@@ -69,6 +69,8 @@ static __device__ __forceinline__ bf16x8 resid_scale(const float (&f8)[8], const
 
 // One row of resid_norm as a device function (`red`: 16 floats of LDS); called by resid_norm_kernel (one workgroup per
 // row).  All threads of the workgroup must call it together.
+// XN_SC1: xn stored write-through (sc1) for consumer workgroups of the SAME launch (lm_stream.hip)
+template <bool XN_SC1 = false>
 static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, const int row, float* red) {
     const int nch = a.H >> 3;
     float ss = 0.f;
@@ -87,7 +89,8 @@ static __device__ __forceinline__ void resid_norm_row(const ResidNormArgs& a, co
                 const bf16x8 o = resid_scale(f8, wv, rstd);
                 // xkb: xn k-blocked [H/32][xkb rows][32] for the mid-M GEMM (gemm_wl.hip), else row-major
                 const long xo = a.xkb ? ((long)(c >> 2) * a.xkb + row) * 32 + (c & 3) * 8 : (long)row * a.ldx + c * 8;
-                *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
+                if constexpr (XN_SC1) store16_sc1(a.xn, xo * 2, __builtin_bit_cast(u32x4_t, o));
+                else *reinterpret_cast<bf16x8*>(a.xn + xo) = o;
             }
             return;
         }

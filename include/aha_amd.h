@@ -106,9 +106,10 @@ int aha_ctx_has_rerotation_table(aha_ctx* ctx, int window, int n_sink, int T);
  *                     directly, not replayed from a graph, so the events are live
  *   "pool_subset"     1 (default): the projector runs only on the patch rows that bilinear pooling with an even integer stride samples
  *                     (24 -> 6: 144 of 576 per frame); bit-identical embeddings
- *   "engine"          1: single-stream steps (<= 48 rows) run each layer's MLP half - post-attention resid_norm, gate/up + SwiGLU,
- *                     down_proj - as ONE persistent launch on an LDS-DMA weight ring (lm_engine.hip); bit-identical to the launches;
- *                     0 (default): the launches (the engine measured slower: profiles/r06_engine_mlp_stamps.txt)
+ *   "engine"          round-6 experiments on single-stream steps (<= 48 rows), bit-identical to the launches, neither ahead of them
+ *                     (profiles/r06_engine_mlp_stamps.txt): 1 = each layer's post-attention resid_norm, gate/up + SwiGLU and down_proj as ONE
+ *                     persistent launch on an LDS-DMA weight ring (lm_engine.hip); 2 = gate/up + SwiGLU and down_proj as one launch
+ *                     whose weight stream runs ahead of the hand-off in registers (lm_stream.hip); 0 (default): the launches
  *   "static_attn"     1 (default): frozen TrulyStaticCache steps whose prefix is <= 64 keys run qkv_finish + attention as one launch
  *   "attn_lm"         LM attention kernel for frame-sized steps: 0 attn_fwd_kernel always, 1 auto (default), 2 attn_lm_kernel always
  *   "use_wl"          1 (default): row chunks above 128 use the mid-M GEMM kernel (both operands staged through LDS); 0: never.

@@ -192,9 +192,10 @@ def test_tail_final_norm_and_heads_flat_bounds_and_score_fraction(full):
 
 
 def test_layer_engine_gives_the_bits_of_the_launches_it_replaces(full):
-    """The persistent MLP-half launch (lm_engine.hip, tuning "engine"; opt-in since it measured slower) against the three launches: same
-    slab sums, same k-step order, same roundings -> every tap, the heads and the scores bit for bit, 28 layers deep, for a frame
-    (36 rows), a single token and a full 48-row step, also when replayed from a captured graph."""
+    """The two round-6 single-launch forms of the layer's MLP half (tuning "engine": 1 = lm_engine.hip, LDS-DMA loader ring incl. the row
+    phase; 2 = lm_stream.hip, register-streaming gate/up -> down_proj; both opt-in: neither measured ahead) against the launches: same slab
+    sums, same k-step order, same roundings -> every tap, the heads and the scores bit for bit, 28 layers deep, for a frame (36 rows), a
+    single token and a full 48-row step, also when replayed from a captured graph."""
     cfg, rt, _ob, _w = full
     H = cfg.lm.hidden_size
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -204,7 +205,7 @@ def test_layer_engine_gives_the_bits_of_the_launches_it_replaces(full):
         for T in (36, 1, 48):
             x = (torch.randn(1, T, H, generator=g, device="cuda") * 0.05).bfloat16()
             outs = {}
-            for lv in (0, 1):
+            for lv in (0, 1, 2):
                 rt.set_tuning("engine", lv)
                 sc, raw, hid = rt.lm_step([st], x, want_raw=True, want_hidden=True)
                 outs[lv] = {"scores": sc.clone(), "raw": raw.clone(), "hid": hid.clone()}
@@ -213,9 +214,10 @@ def test_layer_engine_gives_the_bits_of_the_launches_it_replaces(full):
                 replay = [rt.lm_step([st], x).clone() for _ in range(3)]           # the third call runs the captured graph
                 outs[lv]["replay"] = replay[-1]
                 assert torch.equal(replay[0], replay[-1])
-            for k in outs[0]:
-                assert not torch.isnan(outs[1][k].float()).any(), (T, k)
-                assert torch.equal(outs[0][k], outs[1][k]), f"T={T} {k}: engine differs from the launches"
+            for lv in (1, 2):
+                for k in outs[0]:
+                    assert not torch.isnan(outs[lv][k].float()).any(), (T, lv, k)
+                    assert torch.equal(outs[0][k], outs[lv][k]), f"T={T} {k}: engine {lv} differs from the launches"
     finally:
         rt.set_tuning("engine", 0)
 

@@ -27,9 +27,14 @@ buf = torch.zeros((n_cu, 16), dtype=torch.int64, device="cuda")
 for _ in range(3):
     rt.lm_step([st], x)
 rt._chk(rt.lib.aha_lm_engine_stamps(rt.ctx, buf.data_ptr()))
+LEVEL = 1
 NAMES = {0: "loader start", 1: "gate/up last slot issued", 2: "down last slot issued", 3: "loader drained", 4: "gate/up X published (rows done seen)",
          5: "down X published (slice done seen)", 6: "gate/up first slot in hand", 7: "gate/up last slot consumed", 8: "activation published",
          9: "down first slot in hand", 10: "down last slot consumed", 12: "row normalised (row workgroups)", 13: "workgroup done", 14: "row: slab loads issued", 15: "row: sums exchanged"}
+if any(kv == "engine=2" for kv in sys.argv[1:]):      # lm_stream.hip: the same slots, read as
+    NAMES.update({0: "workgroup start", 1: "gate/up prefetch issued, waiting for the rows", 2: "down prefetch issued, waiting for the slice", 6: "gate/up first X chunk staged",
+                  7: "gate/up last chunk computed + act stored", 9: "down first X chunk staged", 10: "down last chunk computed + slabs stored"})
+    NAMES.pop(3, None)
 for rep in range(3):
     buf.zero_()
     rt.lm_step([st], x); torch.cuda.synchronize()
