@@ -481,6 +481,20 @@ def main():
         kinds[name] = {"ms": round(ms, 4), "launches": n, "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
     rt.set_tuning("time_gemm", 0)
 
+    # [r6] the two single-launch forms of the layer's MLP half (tuning "engine"; opt-in, bit-identical: tests/test_gpu_layers.py) against the launches:
+    # the same F LM steps by HIP events, alternated twice in this process - the driver-run record of profiles/r06_engine_mlp_stamps.txt
+    engines_datum = None
+    if secondary and a.cache == "static":
+        res = {0: [], 1: [], 2: []}
+        for _ in range(2):
+            for lv in (0, 1, 2):
+                rt.set_tuning("engine", lv)
+                res[lv].append(ev_ms(lm_pass, 2) / F)
+        rt.set_tuning("engine", 0)
+        engines_datum = {"what": "one whole LM step (ms, HIP events, graph replay, two alternated samples each): the launches (shipped) / lm_engine.hip "
+                                 "(LDS-DMA loader ring: resid_norm + gate/up + down_proj in one launch) / lm_stream.hip (register-streaming gate/up -> down_proj)",
+                         "launches_ms": res[0], "engine1_ring_ms": res[1], "engine2_stream_ms": res[2]}
+
     static_batched = sink_datum = eight_datum = logits_datum = growing_datum = None
     if configs3:
         wl.close()
@@ -548,6 +562,7 @@ def main():
             "growing_600": growing_datum,
             "eight_stream_sink": eight_datum,
             "ref_so400m_384": ref_datum,
+            "layer_engines": engines_datum,
             "lm_step": {"weight_bytes": wb, "kv_bytes": kvb, "flops": fl, "gemm_kinds": kinds},
         }
         if want_cpu:
