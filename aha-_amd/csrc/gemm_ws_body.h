@@ -104,32 +104,40 @@ static __device__ __forceinline__ void gemm_ws_body(const GemmWsArgs& a, const i
         __syncthreads();
         int c = c0, buf = 0;
         const int steady = n > 2 ? n - 2 : 0;                   // steps that prefetch chunk c+2
-        const int pre = steady % 3;
-        for (int i = 0; i < pre; ++i) {                         // remainder, rotate-by-copy form
-            WS_STEP(wA, wC, buf)
-#pragma unroll
-            for (int ii = 0; ii < KC; ++ii)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) { wA[ii][j] = wB[ii][j]; wB[ii][j] = wC[ii][j]; }
-            buf ^= 1;
-        }
         for (int g = steady / 3; g > 0; --g) {                  // straight-line group of 3 steps
             WS_STEP(wA, wC, buf)
             WS_STEP(wB, wA, buf ^ 1)
             WS_STEP(wC, wB, buf)
             buf ^= 1;
         }
-        // fixed tail: current = wA, next (if any) = wB
+        // The remainder (steady % 3 prefetching steps) runs as the first steps of one more group, then the last two chunks - straight-line
+        // code per remainder, the register sets never copied.  [r6] Rounds 1-5 peeled the remainder at the FRONT in rotate-by-copy form
+        // (wA = wB; wB = wC after each step): the copy reads the set whose load was issued a few instructions earlier, i.e. every such step
+        // waited a full memory latency - two of QKV's four chunks, two of o_proj's, two of gate/up's 28.
+        // tail: two chunks left, W0 = current, W1 = next
+#define WS_TAIL2(W0, W1, BUFX)                     \
+    stage_load(c + 1);                             \
+    compute(W0, (BUFX));                           \
+    stage_store((BUFX) ^ 1);                       \
+    __syncthreads();                               \
+    compute(W1, (BUFX) ^ 1);
         if (n > 1) {
-            stage_load(c + 1);
-            compute(wA, buf);
-            stage_store(buf ^ 1);
-            __syncthreads();
-            compute(wB, buf ^ 1);
+            const int r = steady % 3;
+            if (r == 0) {
+                WS_TAIL2(wA, wB, buf)
+            } else if (r == 1) {
+                WS_STEP(wA, wC, buf)
+                WS_TAIL2(wB, wC, buf ^ 1)
+            } else {
+                WS_STEP(wA, wC, buf)
+                WS_STEP(wB, wA, buf ^ 1)
+                WS_TAIL2(wC, wA, buf)
+            }
         } else {
             compute(wA, buf);
         }
     }
+#undef WS_TAIL2
 #undef WS_STEP
     if (!wave_active) return;
 
