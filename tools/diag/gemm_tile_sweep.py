@@ -8,7 +8,7 @@ lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [c
 _raw = lib.aha_dev_gemm_tile
 def dev_gemm(A, W, C, M, N, K, v, st):
     return _raw(A, W, C, M, N, K, 12 if v == 13 else v, st)
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 5, 8, 14]
 Ms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [576, 1152, 2304, 4608, 18432]
 shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
 if len(sys.argv) > 3 and sys.argv[3] == "so400m":

@@ -6,7 +6,7 @@ import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = ctypes.CDLL(os.path.join(ROOT, "aha-_amd", "libaha_amd.so"))
 lib.aha_dev_gemm_tile.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
-variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [5, 14, 4, 3, 2, 8]
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [5, 14, 21, 2, 8]        # variants 3 / 4 / 6 / 7 / 9 were removed in round 6 (never selected)
 Ms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [288]
 shapes = [(4608, 3584), (3584, 3584)]
 NW = 28
