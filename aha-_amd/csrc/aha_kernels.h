@@ -115,7 +115,7 @@ struct EngArgs {
     int M, grid, n_gemm;
     EngGemm gemm[4];
     const EngAssign* asg;            // [n_gemm][grid]
-    unsigned* sync;                  // this launch's counters, one per 128-byte line, zeroed before the step
+    unsigned* sync;                  // this launch's counters, one per 128-byte line ([32 * 15]: workgroups finished - the last one zeroes the block again)
     int* err;                        // sticky device error word (heads_kernel poisons the scores when set)
     unsigned long long* stamps;      // diagnostic: [grid][16] wall-clock stamps (null in the product)
     int exp;                         // experiment bits (tuning "engine_exp")
@@ -127,7 +127,7 @@ struct MlpStreamArgs {
     int M;
     int gu_blocks, gu_wpb;           // gate/up: workgroups and waves per workgroup that own a pair (237 x 5 at Qwen2-7B)
     int dn_bx, dn_wpb;               // down_proj: workgroups per K slice and tiles (= waves with a tile) per workgroup; the last wave of a workgroup never owns tiles: it polls
-    unsigned* sync;                  // [32 * (1 + s)]: gate/up pairs done of down_proj slice s; zeroed before the step
+    unsigned* sync;                  // [32 * (1 + s)]: gate/up pairs done of down_proj slice s; [32 * 15]: workgroups finished - the last one zeroes the block again
     int* err;                        // sticky device error word
     unsigned long long* stamps;      // diagnostic: [grid][16] wall-clock stamps (null in the product)
 };

@@ -125,7 +125,7 @@ struct aha_ctx {
     // experiments, not the product path (profiles/r06_engine_mlp_stamps.txt).
     int engine = 0;
     bf16 *eng_xn = nullptr, *eng_act = nullptr;             // hand-off panels [K/32][48][32]
-    unsigned* eng_sync = nullptr;                           // [layers][16 counters, one per 128-byte line], zeroed once per step
+    unsigned* eng_sync = nullptr;                           // [layers][16 counters, one per 128-byte line], zero between launches (the kernels reset them on the way out)
     EngAssign* eng_asg = nullptr;                           // device copy of eng_host
     std::vector<EngAssign> eng_host;                        // [phase][workgroup]
     int eng_epoch = -1, eng_grid = 0, eng_G = 0; bool eng_ok = false;

@@ -337,7 +337,6 @@ extern "C" int aha_lm_step(aha_ctx* c, aha_stream* const* streams, int B, const 
     const bool use_eng = !use_st && c->engine == 1 && M <= aha_lm_engine_rows() && !c->time_gemm && pick_split(c, GK_O, c->L[0].o, M, 1) <= 8 && eng_prepare(c) && pick_split(c, GK_DOWN, c->L[0].down, M, 1) == c->eng_G;
     c->eng_ran = use_eng ? M : 0;
     auto layers_and_heads = [&](hipStream_t st, float* scores_out) -> int {
-        if (use_eng || use_st) HIPCHK(c, hipMemsetAsync(c->eng_sync, 0, (size_t)d.layers * 512 * sizeof(unsigned), st));
         // ---- first RMSNorm (the residual stream c->h already holds the embeddings)
         HIPCHK(c, aha_rmsnorm(c->h, H, c->L[l_first].ln1, c->xn, H, M, H, d.rms_eps, st));
 

@@ -462,6 +462,16 @@ __global__ __launch_bounds__(ENG_THREADS, 1) void lm_engine_kernel(EngArgs a) {
         }
         if (cw == 0) eng_stamp(a, 13, lane);
     }
+    // the counters clean up after themselves: the last workgroup to get here zeroes them for the next launch on this block (a memset node in
+    // front of the step's graph did not do under graph replay: tools/diag/race_screen.py)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.sync + 32 * 15, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            for (int s = 0; s < 15; ++s) __hip_atomic_store(a.sync + 32 * s, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 32 * 15, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 extern "C" int aha_lm_engine_lds_bytes() { return ENG_LDS; }

@@ -298,6 +298,17 @@ __global__ __launch_bounds__(ST_THREADS, 1) void lm_mlp_stream_kernel(MlpStreamA
             p.dn, (wave < p.dn_wpb && tile0 < p.dn.n_tiles) ? tile0 : -1, by, xs, [&] { ST_STAMP(2); st_wait(p.sync + 32 * (1 + by), (unsigned)(slice_lo(by + 1) - slice_lo(by)), gerr); ST_STAMP(5); }, [&] { ST_STAMP(10); }, p.stamps);
     }
     ST_STAMP(13);
+    // The counters clean up after themselves: the last workgroup to get here (every workgroup of the grid passes, with or without work) zeroes
+    // them for the next launch that uses this block.  [r6] A memset node in front of the step's graph did not do: under graph replay the hand-offs
+    // intermittently read early or timed out (tools/diag/race_screen.py), never with direct launches.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.sync + 32 * 15, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            for (int s = 0; s < p.dn.S; ++s) __hip_atomic_store(p.sync + 32 * (1 + s), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.sync + 32 * 15, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Shapes the instantiated pipeline depths serve (lm_mlp_stream_kernel: gate/up NS 5 / KC 4 with remainder 4; down_proj NS 5 / KC 8 with remainder

@@ -65,5 +65,37 @@ for n in (32, 8, 1, 3):
     n_bad = sum(int(not torch.equal(rt.visual_embed(fr), ref)) for _ in range(rounds))
     total += rounds; bad += n_bad
     print(f"vision encode n={n} (k-blocked operands, riders, head-resident attention vs row-major, none, restaging): {n_bad} of {rounds} encodes differ", flush=True)
+rt.close()
+# [r6] the two single-launch MLP forms (tuning "engine": 1 = LDS-DMA loader ring with in-launch row phase, 2 = register-streaming gate/up -> down_proj):
+# persistent workgroups that hand tiles to each other through write-through stores + counters - the most race-prone code in the library.  Every step's
+# scores AND final hidden row against the launches', full model, direct launches (hidden requested) and graph replay, inputs alternating so that a stale
+# hand-off buffer of the previous step would show; once idle and once with a second stream keeping the memory system busy (cdna_hip_programming.md G16:
+# "test under uniform AND uneven load").
+cfg = preset("bench"); tf, H = cfg.frame_num_tokens, cfg.lm.hidden_size
+rt = Runtime(cfg, make_weights(cfg, device="cuda", dtype=torch.bfloat16, skip_lm_head=True), max_step_tokens=128, max_vit_frames=1)
+st = rt.open_stream("static", 2048, 0)
+rt.lm_step([st], (torch.randn(1, 20, H, generator=g, device="cuda") * 0.05).bfloat16())
+xs = [(torch.randn(1, T, H, generator=g, device="cuda") * 0.05).bfloat16() for T in (tf, tf, 1, 48, tf)]
+rt.set_tuning("engine", 0)
+ref = [tuple(t.clone() for t in rt.lm_step([st], x, want_hidden=True)) for x in xs]
+noise_src = torch.empty(64 << 20, dtype=torch.uint8, device="cuda"); noise_dst = torch.empty_like(noise_src)
+side = torch.cuda.Stream()
+for lv in (1, 2):
+    rt.set_tuning("engine", lv)
+    for load in (False, True):
+        n_bad = 0
+        for r in range(rounds):
+            if load:
+                with torch.cuda.stream(side):
+                    for _ in range(4): noise_dst.copy_(noise_src)
+            for i, x in enumerate(xs):
+                sc, hid = rt.lm_step([st], x, want_hidden=True)              # direct launches
+                n_bad += int(not (torch.equal(sc, ref[i][0]) and torch.equal(hid, ref[i][1])))
+                sc2 = rt.lm_step([st], x)                                      # graph replay from the second time on
+                n_bad += int(not torch.equal(sc2, ref[i][0]))
+        torch.cuda.synchronize()
+        total += rounds * len(xs) * 2; bad += n_bad
+        print(f"layer engine {lv} ({'beside a copy stream' if load else 'alone'}): {n_bad} of {rounds * len(xs) * 2} steps differ from the launches", flush=True)
+rt.set_tuning("engine", 0)
 print(f"RACE SCREEN: {bad} differing launches of {total}")
 sys.exit(1 if bad else 0)
