@@ -15,7 +15,7 @@ Fixtures are data (seeds, inputs, expected outputs), never reference source text
                        theta 1e6, 4 KV heads; chunks 20, 71, then 36 x 120: every key lives its whole ~55 bf16 re-rotations):
                        per step and layer the sha256 of the returned K and V bits, plus sampled rows.
   ref_functions.json   outputs of three pure functions of the reference, compiled UNMODIFIED from their source text with `ast` and
-  ref_pooling.npz      executed here (post_projector_pooling, round_numbers / truncate_sig, find_ticks); the fixtures hold inputs'
+  ref_pooling.npz      executed here (post_projector_pooling, round_numbers / truncate_sig, find_ticks, knapsack_selection); the fixtures hold inputs'
                        seeds and outputs only.
   frame_ingest.npz     canvases produced by Pillow itself (Image.resize default BICUBIC + ImageOps.expand, the
                        calls of LiveInferForDemo.load_one_frame) for seeded uint8 frames at S = 56 / 84.
@@ -170,6 +170,17 @@ def ticks_input(i):
     return np.round(base, 3)
 
 
+def knapsack_input(i):
+    """Seeded frame rows in the reference's debug_data schema, with ties in the scores (rounded to 2 dp) so that the tie rule matters."""
+    rng = np.random.RandomState(300 + i)
+    n = 40 + 25 * i
+    return [{"idx": int(k), "informative_score": float(np.round(rng.rand(), 2)), "relevance_score": float(np.round(rng.rand(), 2)),
+             "uncertainty_score": float(np.round(rng.rand() * 2, 2))} for k in range(n)]
+
+
+KNAPSACK_CASES = [(0, 7, 1.0, 1.0, 0.5, -0.2), (0, 0, 1.0, 1.0, 0.5, -0.2), (1, 15, 1.0, 0.0, -1.0, -5.0), (1, 64, 1.0, 0.3, 0.7, 0.0), (2, 200, 1.0, 1.0, 1.0, 1.0)]
+
+
 def gen_ref_functions():
     import json
     import math
@@ -181,6 +192,7 @@ def gen_ref_functions():
     exec(_ref_function("/root/reference/test/inference.py", "truncate_sig"), ns)
     exec(_ref_function("/root/reference/test/inference.py", "round_numbers"), ns)
     exec(_ref_function("/root/reference/test/live_infer_for_video.py", "find_ticks"), ns)
+    exec(_ref_function("/root/reference/test/highlight_generator.py", "knapsack_selection"), ns)
     pools = {}
     for grid, stride, mode in POOL_CASES:
         me = types.SimpleNamespace(config=types.SimpleNamespace(video_pooling_stride=stride, mm_spatial_pool_mode=mode),
@@ -194,7 +206,8 @@ def gen_ref_functions():
     for i in range(2):
         for fps in (1.0, 2.0):
             ticks.append({"case": i, "fps": fps, "peaks": [float(t) for t in ns["find_ticks"](None, ticks_input(i), fps)]})
-    json.dump({"round_numbers_3": rounded, "round_types": [type(v).__name__ for v in rounded], "find_ticks": ticks},
+    knap = [sorted(int(v) for v in ns["knapsack_selection"](knapsack_input(i), budget, w, al, be, ep)) for i, budget, w, al, be, ep in KNAPSACK_CASES]
+    json.dump({"round_numbers_3": rounded, "round_types": [type(v).__name__ for v in rounded], "find_ticks": ticks, "knapsack_selection": knap},
               open(os.path.join(OUT, "ref_functions.json"), "w"), indent=1)
     print("ref_pooling.npz", {k: v.shape for k, v in pools.items()})
     print("ref_functions.json", rounded, ticks)

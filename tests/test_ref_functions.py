@@ -3,7 +3,8 @@ unmodified from its source text (`ast`, no import of the file) and stores output
 ref_functions.json).  Here the oracle's restatement and the product's host code must reproduce them:
   post_projector_pooling   /root/reference/models/live_llava/video_head_live_llava_qwen.py:117-136
   round_numbers / truncate_sig   /root/reference/test/inference.py:359-375
-  find_ticks               /root/reference/test/live_infer_for_video.py:195-228"""
+  find_ticks               /root/reference/test/live_infer_for_video.py:195-228
+  knapsack_selection       /root/reference/test/highlight_generator.py:8-37"""
 import json
 import os
 import sys
@@ -50,3 +51,15 @@ def test_find_ticks_of_the_product_reproduces_the_reference_function():
         scores = mg.ticks_input(case["case"])
         assert [float(t) for t in LiveInferForDemo.find_ticks(None, scores, case["fps"])] == case["peaks"]
         assert [float(t) for t in LiveInferForDemo.find_ticks(None, list(scores), case["fps"], min_separation=3)] == case["peaks"]   # the reference overrides the argument
+
+
+def test_knapsack_selection_of_the_product_reproduces_the_reference_function():
+    """Unit-cost 0/1 knapsack over alpha * informative + beta * relevance + epsilon * uncertainty with the reference's tie rule (a frame is
+    taken iff it changed the DP cell, walking back from the last frame): same selected index sets on seeded rows with tied scores."""
+    gold = json.load(open(os.path.join(GOLDEN, "ref_functions.json")))
+    import aha_amd  # noqa: F401
+    from aha_amd import postproc as pp
+    for (i, budget, w, al, be, ep), want in zip(mg.KNAPSACK_CASES, gold["knapsack_selection"]):
+        got = pp.knapsack_selection(mg.knapsack_input(i), budget, w, al, be, ep)
+        assert sorted(int(v) for v in got) == want, (i, budget)
+        assert len(want) == min(budget, len(mg.knapsack_input(i))) or any(v <= 0 for v in (al, be, ep))
