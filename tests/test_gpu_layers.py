@@ -218,6 +218,20 @@ def test_layer_engine_gives_the_bits_of_the_launches_it_replaces(full):
                 for k in outs[0]:
                     assert not torch.isnan(outs[lv][k].float()).any(), (T, lv, k)
                     assert torch.equal(outs[0][k], outs[lv][k]), f"T={T} {k}: engine {lv} differs from the launches"
+        # ... and on an evicting SinkCache (the engines replace launches that do not touch the cache, but the step around them differs: tile
+        # attention + combine instead of the fused static kernel, re-rotation in front): six frames through W = 128, every score equal
+        xs = [(torch.randn(1, 36, H, generator=g, device="cuda") * 0.05).bfloat16() for _ in range(6)]
+        want = None
+        for lv in (0, 1, 2):
+            rt.set_tuning("engine", lv)
+            sk = rt.open_stream("default_sink", 128, 8)
+            got = torch.stack([rt.lm_step([sk], x).clone() for x in xs])
+            assert sk.get_seq_length() == 128 and torch.isfinite(got).all()
+            sk.close()
+            if want is None:
+                want = got
+            else:
+                assert torch.equal(got, want), f"engine {lv} differs from the launches on the SinkCache stream"
     finally:
         rt.set_tuning("engine", 0)
 
