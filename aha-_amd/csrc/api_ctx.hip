@@ -145,7 +145,12 @@ extern "C" int aha_ctx_set_tuning(aha_ctx* c, const char* key, int value) {
     else if (k == "vit_riders") c->vit_riders = value < 0 ? 0 : (value > 1024 ? 1024 : value);   // rider workgroups per prefetching launch
     else if (k == "vit_alias") c->vit_alias = value;              // diagnostic (tools/diag/vit_alias.py): wrong embeddings on purpose
     else if (k == "engine_exp") c->eng_exp = value;
-    else if (k == "engine") c->engine = value;                    // single-launch MLP-half experiments on single-stream steps: 1 lm_engine.hip, 2 lm_stream.hip; default 0
+    else if (k == "engine") {
+        c->engine = value;
+        // a hand-off that timed out inside an engine launch set the sticky error word (NaN scores from then on): choosing an engine level again
+        // - 0 included - clears it, so that the experiment cannot leave a context unusable
+        if (c->bar_err) { hipDeviceSynchronize(); hipMemset(c->bar_err, 0, sizeof(int)); }
+    }                    // single-launch MLP-half experiments on single-stream steps: 1 lm_engine.hip, 2 lm_stream.hip; default 0
     else if (k == "use_graph") c->use_graph = value;              // 1 (default): replay frozen-static steps from a captured HIP graph
     else if (k == "kc_small") aha_gemm_ws_set_kc_small(value);
     else if (k == "attn_lm") aha_attention_set_lm_kernel(value);   // 1 (default): frame-sized LM steps use attn_lm_kernel (LDS-DMA, all row tiles per workgroup)
