@@ -435,7 +435,9 @@ static __device__ __forceinline__ void attn_dense_body(const AttnArgs& a, const 
             // a row that has seen no key yet (m_new = -inf: only while every key so far was masked) takes alpha = 1 and the offset 0, so
             // that its probabilities are 2^(-inf) = 0 without a branch (the branch cost eleven register presets per tile in every block)
             const bool unseen = m_new == -INFINITY;
-            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf, m_new finite -> 0
+            // (the difference is taken on a sanitised operand: -inf - -inf of an unseen row would be a NaN on the unselected arm, which this file's
+            // -fno-honor-nans lets the compiler treat as poison - ADVICE r5)
+            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f((unseen ? 0.f : m_run[tt]) - m_new);   // m_run = -inf, m_new finite -> 0
             const float nm = unseen ? 0.f : -m_new;
             float psum = 0.f;
 #pragma unroll
@@ -645,7 +647,9 @@ __global__ __launch_bounds__(64 * NW) void attn_head64_kernel(AttnArgs a, int lk
             // a row that has seen no key yet (m_new = -inf: only while every key so far was masked) takes alpha = 1 and the offset 0, so
             // that its probabilities are 2^(-inf) = 0 without a branch (the branch cost eleven register presets per tile in every block)
             const bool unseen = TAIL && m_new == -INFINITY;
-            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f(m_run[tt] - m_new);   // m_run = -inf, m_new finite -> 0
+            // (the difference is taken on a sanitised operand: -inf - -inf of an unseen row would be a NaN on the unselected arm, which this file's
+            // -fno-honor-nans lets the compiler treat as poison - ADVICE r5)
+            const float alpha = unseen ? 1.f : __builtin_amdgcn_exp2f((unseen ? 0.f : m_run[tt]) - m_new);   // m_run = -inf, m_new finite -> 0
             const float nm = unseen ? 0.f : -m_new;
             float psum = 0.f;
 #pragma unroll
